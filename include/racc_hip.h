@@ -1,0 +1,156 @@
+/*
+ * racc_hip.h — C-ABI of the MI355X (gfx950) intersect-batch engine.
+ *
+ * This is the boundary the reference's host code would bind instead of its
+ * OpenCL calls: plain pointers and sizes, `int` status (0 = ok, <0 = error,
+ * text via racc_hip_last_error()), never throws, no torch/HIP types in any
+ * signature.  Each entry cites the reference interface it replaces
+ * (file:line relative to the reference checkout).  The reference-side stubs a
+ * maintainer would add are shown in INTEGRATION.md.
+ *
+ * Record layouts are the reference's, byte for byte:
+ *   Ray     32 B  {origin[3], minT, dir[3], maxT}         RayAccelerator.h:59-64
+ *   Result  16 B  {u32 triangle; t,u,v | r,g,b}           RayAccelerator.h:66-76
+ *                 triangle == 0xFFFFFFFF => miss, floats = environment rgb
+ *   Node    64 B  {kind,parent,first,last, leftMin[3],leftMax[3],
+ *                  rightMin[3],rightMax[3]}                Scene.cpp:73-78
+ *   Pair    48 B  {e1.xyz,e3.x, e2.xyz,e3.y, p0.xyz,e3.z}  Scene.cpp:83-87
+ *   remap   u32   tri | edge<<30, two per pair             Scene.cpp:132-133
+ */
+#ifndef RACC_HIP_H
+#define RACC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RACC_HIP_OK                 0
+#define RACC_HIP_ERR_INVALID       -1   /* bad argument / malformed scene blob */
+#define RACC_HIP_ERR_DEVICE        -2   /* a HIP call failed */
+#define RACC_HIP_ERR_NO_DEVICE     -3   /* no gfx950 device / extension unusable */
+#define RACC_HIP_ERR_LIMIT         -4   /* scene exceeds a format limit (Scene.cpp:294-312) */
+#define RACC_HIP_ERR_NOMEM         -5
+
+#define RACC_HIP_MAX_LANES          8   /* >= gpuSubmissionThreads (RayAccelerator.cpp:436) */
+
+typedef struct racc_hip_ctx   racc_hip_ctx;    /* one per (process, GPU) */
+typedef struct racc_hip_scene racc_hip_scene;  /* device-resident flattened BVH2 + pairs */
+typedef struct racc_hip_env   racc_hip_env;    /* device-resident RGBA32F probe image */
+typedef struct racc_host_scene racc_host_scene;/* host-side build product (reference-format blobs) */
+
+typedef struct racc_hip_options {
+    uint32_t struct_size;      /* = sizeof(racc_hip_options) */
+    uint32_t lanes;            /* concurrent submission lanes, each with its own HIP stream
+                                  (≙ gpuSubmissionThreads queues, RayAccelerator.cpp:711-717); 0 => 4 */
+    uint32_t waves_per_simd;   /* persistent-grid occupancy target, 1..8; 0 => engine default */
+    uint32_t kernel_variant;   /* 0 => engine default; see DESIGN.md "kernel variants" */
+    uint32_t refill_min;       /* idle lanes that trigger a wave refill; 0 => default */
+    uint32_t leaf_min;         /* leaf-holding lanes that trigger a leaf step; 0 => default */
+    uint32_t chunk;            /* rays a wave dequeues per cursor atomic; 0 => default */
+    uint32_t reserved[9];
+} racc_hip_options;
+
+typedef struct racc_hip_scene_info {
+    uint32_t node_count;       /* inner nodes */
+    uint32_t pair_count;       /* pairs incl. padding */
+    uint32_t remap_count;
+    uint32_t inner_height;     /* levels of inner nodes on the longest root path */
+    uint32_t max_leaf_pairs;
+    uint32_t spill_levels;     /* stack levels beyond the LDS-resident ones */
+    uint64_t device_bytes;
+} racc_hip_scene_info;
+
+/* Per-launch counters of the last racc_hip_intersect_device* call on a lane (debug/bench). */
+typedef struct racc_hip_launch_info {
+    uint32_t grid_blocks, block_threads;
+    uint32_t lds_bytes_per_block;
+    uint32_t waves_per_simd;
+    float    last_kernel_ms;   /* hipEvent time of the traversal kernel alone */
+} racc_hip_launch_info;
+
+const char* racc_hip_last_error(void);             /* thread-local, never NULL */
+const char* racc_hip_version(void);
+
+/* ≙ clGetDeviceIDs, RayAccelerator.cpp:467-478 (reference picks devices[0]). */
+int racc_hip_device_count(int* count);
+
+/* ≙ racc::createContext's OpenCL half: program build + queues, RayAccelerator.cpp:463-514,700-717.
+ * Fails with RACC_HIP_ERR_NO_DEVICE if `device` is not a gfx950 GPU: there is no CPU fallback. */
+int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out);
+int racc_hip_destroy(racc_hip_ctx* ctx);           /* ≙ racc::destroy(Context*), RayAccelerator.cpp:761-788 */
+
+/* ≙ the three clCreateBuffer(COPY_HOST_PTR) calls, Scene.cpp:342-346.  Inputs are the
+ * reference-format blobs (copied; caller keeps ownership).  The blob is validated
+ * (child indices, pair ranges, no cycles) and re-laid-out for the device. */
+int racc_hip_scene_upload(racc_hip_ctx* ctx,
+                          const void* nodes64, uint32_t node_count,
+                          const void* pairs48, uint32_t pair_count,
+                          const uint32_t* remap, uint32_t remap_count,
+                          racc_hip_scene** out);
+int racc_hip_scene_free(racc_hip_ctx* ctx, racc_hip_scene* scene);   /* ≙ Scene.cpp:362-369 */
+int racc_hip_scene_get_info(const racc_hip_scene* scene, racc_hip_scene_info* info);
+
+/* ≙ clCreateImage(RGBA, FLOAT), Environment.cpp:36-50.  rgba is width*height*4 floats, copied. */
+int racc_hip_env_upload(racc_hip_ctx* ctx, const float* rgba, uint32_t width, uint32_t height, racc_hip_env** out);
+int racc_hip_env_free(racc_hip_ctx* ctx, racc_hip_env* env);         /* ≙ Environment.cpp:63-64 */
+
+/* ≙ clCreateBuffer(CL_MEM_USE_HOST_PTR) per ray stream, RayAccelerator.cpp:635-645: page-locks the
+ * stream's host arrays so the copies below run at PCIe rate.  Optional. */
+int racc_hip_register_stream(racc_hip_ctx* ctx, void* rays, void* results, uint32_t capacity);
+int racc_hip_unregister_stream(racc_hip_ctx* ctx, void* rays, void* results);
+
+/* ≙ clSetKernelArg x7 + clEnqueueNDRangeKernel + clFinish on one submission thread's queue,
+ * RayAccelerator.cpp:378-404.  Host Ray[count] in, host Result[count] out, in place and in order
+ * (RayStream contract, RayAccelerator.h:78-83).  `lane` in [0, lanes): calls on distinct lanes may
+ * run concurrently from different threads.  env may be NULL (miss rgb = 0).  Blocking. */
+int racc_hip_intersect(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
+                       const void* rays, void* results, uint32_t count, uint32_t lane);
+/* Same, split into enqueue and wait (≙ clEnqueueNDRangeKernel / clFinish). */
+int racc_hip_intersect_async(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
+                             const void* rays, void* results, uint32_t count, uint32_t lane);
+int racc_hip_wait(racc_hip_ctx* ctx, uint32_t lane);
+
+/* Device-resident variant: d_rays/d_results are device pointers (e.g. torch tensors' data_ptr()).
+ * `stream` is a hipStream_t passed as void* (NULL => the lane's own stream).  Asynchronous. */
+int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
+                              const void* d_rays, void* d_results, uint32_t count,
+                              uint32_t lane, void* stream);
+/* Runs the device variant `iters` times back to back on the lane's stream and writes each launch's
+ * traversal-kernel duration in milliseconds (HIP events on that stream) to ms[iters]. Blocking. */
+int racc_hip_intersect_device_timed(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
+                                    const void* d_rays, void* d_results, uint32_t count,
+                                    uint32_t lane, uint32_t iters, float* ms);
+int racc_hip_get_launch_info(racc_hip_ctx* ctx, uint32_t lane, racc_hip_launch_info* info);
+
+/* Device memory helpers for hosts that do not bring their own allocator. */
+int racc_hip_malloc(racc_hip_ctx* ctx, uint64_t bytes, void** d_ptr);
+int racc_hip_free(racc_hip_ctx* ctx, void* d_ptr);
+int racc_hip_memcpy_h2d(racc_hip_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
+int racc_hip_memcpy_d2h(racc_hip_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
+int racc_hip_synchronize(racc_hip_ctx* ctx);
+
+/* ---- host-side scene build (no GPU needed) ---------------------------------------------------
+ * ≙ the GPU branch of racc::createScene, Scene.cpp:216-339: createBvh2 (Bvh2.cpp:772-907) →
+ * leaf pair merge (Scene.cpp:237-261) → 64 B node flatten (Scene.cpp:275-332) → pair padding
+ * (Scene.cpp:334-338).  vertices: xyzw floats, 16-byte aligned (Scene.cpp:187); index_count % 3 == 0
+ * (Scene.cpp:186).  Deterministic (the reference's node numbering is thread-timing dependent). */
+int racc_host_scene_build(const float* vertices, uint32_t vertex_count,
+                          const uint32_t* indices, uint32_t index_count,
+                          racc_host_scene** out);
+int racc_host_scene_free(racc_host_scene* scene);
+/* Borrowed pointers into the build product, valid until racc_host_scene_free. */
+int racc_host_scene_blobs(const racc_host_scene* scene,
+                          const void** nodes64, uint32_t* node_count,
+                          const void** pairs48, uint32_t* pair_count_padded, uint32_t* pair_count,
+                          const uint32_t** remap, uint32_t* remap_count);
+/* The intermediate BVH2 (Bvh2.h:15-29): 48 B nodes + permuted triangle ids. */
+int racc_host_scene_bvh2(const racc_host_scene* scene,
+                         const void** nodes48, uint32_t* node_count,
+                         const uint32_t** triangles, uint32_t* triangle_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,725 @@
+// racc_hip.hip — gfx950 (MI355X) wavefront BVH2 traversal + the C-ABI around it.
+//
+// Replaces the reference's OpenCL `traversal` kernel (RayAccelerator/Kernels.h:139-242) and its
+// launch path (RayAccelerator/RayAccelerator.cpp:378-404).  Not a translation: the reference runs one
+// work-item per ray in work-groups of 8 with a private int[64] stack and one blocking launch per
+// <=27k-ray stream.  Here:
+//   * persistent waves (wave64) pull rays from a global cursor in chunks and keep their lanes full:
+//     finished lanes are detected with a wave ballot, ranked with mbcnt (prefix sum over the ballot)
+//     and re-loaded with the next rays of the wave's chunk — active-ray compaction at wavefront width;
+//   * each iteration the wave VOTES on what to run: an inner-node step for every lane that holds an
+//     inner node, or a triangle-pair step for every lane that holds a leaf, so neither body is executed
+//     for a handful of lanes ("vote-scheduled while-while"); Moller-Trumbore (the reference's Embree
+//     style pair test, Kernels.h:36-115) is fused into that leaf step;
+//   * the per-ray traversal stack lives in LDS as [level][thread] (bank = thread % 32 at every level, so
+//     pushes/pops never conflict) with a global-memory spill above LDS_LEVELS that is sized from the
+//     real tree height at upload time — unlike the reference's unchecked stack[64] it cannot overflow;
+//   * hit/miss epilogues (remap gather + barycentric rotation, probe-image bilinear) are deferred and
+//     batched into the refill step.
+// Arithmetic is IEEE binary32 with explicit fmaf only (built with -ffp-contract=off, no fast-math), the
+// same evaluation order as oracle/racc_oracle.c, so primId/t/u/v are bit-identical to the CPU
+// restatement for every finite ray.  The traversal ORDER is the reference's (nearer child first, far
+// child pushed only if both hit, pairs of a leaf in order), which is what makes ties resolve identically.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "racc_hip.h"
+
+extern "C" void racc_hip_set_error_(const char* msg);
+
+namespace {
+
+constexpr int kBlock = 256;        // 4 waves: one per SIMD of a CU
+constexpr int kLdsLevels = 16;     // stack levels resident in LDS (16 KiB per block)
+constexpr uint32_t kInvalidTriangle = 0xFFFFFFFFu;
+constexpr uint32_t kLeafBase = 0x1000000u;   // node refs below this carry no work (done / empty lane)
+
+struct TraverseArgs {
+    const float4* rays;
+    float4* results;
+    uint32_t count;
+    const float4* nodes;      // 4 x float4 per inner node (Scene.cpp:73-78 order)
+    const float4* pairs;      // 3 x float4 per pair (Scene.cpp:83-87 order)
+    const uint32_t* remap;
+    const float4* env;        // RGBA32F probe image or nullptr
+    uint32_t envW, envH;
+    uint32_t* cursor;         // [0] ray cursor, [1] finished-block counter
+    uint32_t* spill;          // [spillLevels][gridThreads]
+    uint32_t spillStride;     // gridThreads
+    uint32_t chunk;           // rays per cursor dequeue
+    uint32_t refillMin;       // idle lanes that trigger a refill
+    uint32_t leafMin;         // leaf lanes that trigger a leaf step
+};
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
+}
+
+// Slab test, Kernels.h:117-135.  Returns the entry distance, or tFar as the "missed" sentinel.
+__device__ __forceinline__ float aabbIntersect(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                               float ix, float iy, float iz, float ox, float oy, float oz,
+                                               float tNear, float tFar) {
+    const float ax = __builtin_fmaf(mnx, ix, ox), bx = __builtin_fmaf(mxx, ix, ox);
+    const float ay = __builtin_fmaf(mny, iy, oy), by = __builtin_fmaf(mxy, iy, oy);
+    const float az = __builtin_fmaf(mnz, iz, oz), bz = __builtin_fmaf(mxz, iz, oz);
+    const float t0 = fmaxf(fmaxf(tNear, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
+    const float t1 = fminf(fminf(tFar, fmaxf(ax, bx)), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+    return (t0 > t1) ? tFar : t0;
+}
+
+struct LaneRay {
+    float ox, oy, oz, dx, dy, dz;       // origin, (clamped) direction
+    float ix, iy, iz, ex, ey, ez;       // 1/dir, -origin/dir
+    float tNear, tFar;
+    int hitIndex;                       // pair*2 + which, or -1
+    float hitU, hitV;
+};
+
+// Triangle-pair test, Kernels.h:36-115.  Updates the lane's hit and returns the new tFar.
+__device__ __forceinline__ float pairIntersect(const float4* __restrict__ pairs, uint32_t index, LaneRay& r) {
+    const float4 t0 = pairs[index * 3 + 0];
+    const float4 t1 = pairs[index * 3 + 1];
+    const float4 t2 = pairs[index * 3 + 2];
+    const float tNear = r.tNear, tMax = r.tFar;
+
+    // n1 = e1 x e2, n2 = e3 x e1 (mad_cross, Kernels.h:23-25)
+    const float n1x = __builtin_fmaf(t0.y, t1.z, -(t0.z * t1.y));
+    const float n1y = __builtin_fmaf(t0.z, t1.x, -(t0.x * t1.z));
+    const float n1z = __builtin_fmaf(t0.x, t1.y, -(t0.y * t1.x));
+    const float n2x = __builtin_fmaf(t1.w, t0.z, -(t2.w * t0.y));
+    const float n2y = __builtin_fmaf(t2.w, t0.x, -(t0.w * t0.z));
+    const float n2z = __builtin_fmaf(t0.w, t0.y, -(t1.w * t0.x));
+    const float cx = t2.x - r.ox, cy = t2.y - r.oy, cz = t2.z - r.oz;
+    const float rx = __builtin_fmaf(r.dy, cz, -(r.dz * cy));
+    const float ry = __builtin_fmaf(r.dz, cx, -(r.dx * cz));
+    const float rz = __builtin_fmaf(r.dx, cy, -(r.dy * cx));
+
+    const float det1 = dot3(n1x, n1y, n1z, r.dx, r.dy, r.dz);
+    const float det2 = dot3(n2x, n2y, n2z, r.dx, r.dy, r.dz);
+    const uint32_t sgn1 = __float_as_uint(det1) & 0x80000000u;
+    const uint32_t sgn2 = __float_as_uint(det2) & 0x80000000u;
+
+    const float re1 = dot3(rx, ry, rz, t0.x, t0.y, t0.z);
+    const uint32_t iU1 = __float_as_uint(dot3(rx, ry, rz, t1.x, t1.y, t1.z)) ^ sgn1;
+    const uint32_t iV1 = __float_as_uint(re1) ^ sgn1;
+    const uint32_t iU2 = __float_as_uint(-re1) ^ sgn2;
+    const uint32_t iV2 = __float_as_uint(-dot3(rx, ry, rz, t0.w, t1.w, t2.w)) ^ sgn2;
+
+    bool outside1 = int(iU1 | iV1) < 0;
+    bool outside2 = int(iU2 | iV2) < 0;
+
+    float U1 = __uint_as_float(iU1), V1 = __uint_as_float(iV1);
+    const float U2 = __uint_as_float(iU2), V2 = __uint_as_float(iV2);
+    float absDet1 = fabsf(det1);
+    const float absDet2 = fabsf(det2);
+    const float W1 = absDet1 - U1 - V1;
+    const float W2 = absDet2 - U2 - V2;
+    float T1 = __uint_as_float(__float_as_uint(dot3(n1x, n1y, n1z, cx, cy, cz)) ^ sgn1);
+    const float T2 = __uint_as_float(__float_as_uint(dot3(n2x, n2y, n2z, cx, cy, cz)) ^ sgn2);
+
+    outside1 = outside1 || (W1 < 0.0f || T1 <= absDet1 * tNear || T1 > absDet1 * tMax);
+    outside2 = outside2 || (W2 < 0.0f || T2 <= absDet2 * tNear || T2 > absDet2 * tMax);
+    if (outside1 && outside2) return tMax;
+
+    uint32_t which = 0;
+    if ((!outside2 && outside1) || (!outside1 && !outside2 && T1 * absDet2 > T2 * absDet1)) {
+        absDet1 = absDet2; T1 = T2; U1 = U2; V1 = V2;
+        which = 1;
+    }
+    const float rcp = 1.0f / absDet1;      // correctly rounded (reference: native_recip, Kernels.h:107)
+    const float t = T1 * rcp;
+    r.hitIndex = int(index * 2 + which);
+    r.hitU = U1 * rcp;
+    r.hitV = V1 * rcp;
+    return t;
+}
+
+// Miss colour, Kernels.h:213-222 with OpenCL CLAMP_TO_EDGE | FILTER_LINEAR on normalized coordinates.
+__device__ __forceinline__ float4 envSample(const float4* __restrict__ env, uint32_t envW, uint32_t envH,
+                                             float dx, float dy, float dz) {
+    float4 out = make_float4(__uint_as_float(kInvalidTriangle), 0.0f, 0.0f, 0.0f);
+    if (!env) return out;
+    const float rlen = 1.0f / sqrtf(__builtin_fmaf(dz, dz, dy * dy));
+    float r = (rlen > 1e+6f) ? 0.0f : acosf(-dx) * (1.0f / (2.0f * 3.141593f)) * rlen;
+    if (!isfinite(r)) r = 0.0f;
+    const float u = 0.5f - r * dz, v = 0.5f - r * dy;
+    const float fx = u * float(envW) - 0.5f, fy = v * float(envH) - 0.5f;
+    const float flx = floorf(fx), fly = floorf(fy);
+    const float a = fx - flx, b = fy - fly;
+    const int w1 = int(envW) - 1, h1 = int(envH) - 1;
+    const int x0 = min(max(int(flx), 0), w1), x1 = min(max(int(flx) + 1, 0), w1);
+    const int y0 = min(max(int(fly), 0), h1), y1 = min(max(int(fly) + 1, 0), h1);
+    const float4 t00 = env[size_t(y0) * envW + x0], t10 = env[size_t(y0) * envW + x1];
+    const float4 t01 = env[size_t(y1) * envW + x0], t11 = env[size_t(y1) * envW + x1];
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    out.y = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
+    out.z = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
+    out.w = w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z;
+    return out;
+}
+
+__device__ __forceinline__ uint32_t laneRank(uint64_t mask) {   // # set bits below this lane: prefix sum of the ballot
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
+
+template <int LDS_LEVELS>
+__global__ void __launch_bounds__(kBlock) traverseKernel(const TraverseArgs a) {
+    __shared__ uint32_t ldsStack[LDS_LEVELS * kBlock];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    uint32_t* const myLds = ldsStack + tid;                                  // level stride kBlock
+    uint32_t* const mySpill = a.spill + (blockIdx.x * kBlock + tid);         // level stride a.spillStride
+
+    LaneRay r;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = 0.0f;
+    r.ix = r.iy = r.iz = r.ex = r.ey = r.ez = 0.0f;
+    r.tNear = r.tFar = 0.0f; r.hitIndex = -1; r.hitU = r.hitV = 0.0f;
+    int rayIdx = -1;            // ray owned by this lane, -1 = none
+    uint32_t node = 0;          // bit31: inner ref | >= kLeafBase: leaf with pairs pending | else: no work
+    uint32_t sp = 0;
+    uint32_t wBeg = 0, wEnd = 0;        // wave's private chunk of the batch (wave-uniform)
+    bool exhausted = false;             // wave-uniform: the global cursor ran past the batch
+
+    for (;;) {
+        const uint64_t innerMask = __ballot(int(node) < 0);
+        const uint64_t idleMask = __ballot(node < kLeafBase);
+        const uint32_t nInner = __popcll(innerMask);
+        const uint32_t nIdle = __popcll(idleMask);
+        const uint32_t nLeaf = 64u - nInner - nIdle;
+        const bool noWork = (nInner | nLeaf) == 0u;
+
+        if (noWork || (nIdle >= a.refillMin && !(exhausted && __ballot(rayIdx >= 0 && node < kLeafBase) == 0ull))) {
+            // ---------------- epilogue of finished rays (Kernels.h:213-241), batched ----------------
+            if (rayIdx >= 0 && node < kLeafBase) {
+                float4 out;
+                if (r.hitIndex < 0) {
+                    out = envSample(a.env, a.envW, a.envH, r.dx, r.dy, r.dz);
+                } else {
+                    uint32_t m = a.remap[r.hitIndex];
+                    const uint32_t edge = m >> 30;
+                    m &= 0x3FFFFFFFu;
+                    const float bx = r.hitU, by = r.hitV, bz = 1.0f - r.hitU - r.hitV;
+                    float u = bx, v = by;
+                    if (edge == 1u) { u = bz; v = bx; } else if (edge == 2u) { u = by; v = bz; }
+                    out = make_float4(__uint_as_float(m), r.tFar, u, v);
+                }
+                a.results[rayIdx] = out;
+                rayIdx = -1;
+            }
+            // ---------------- refill idle lanes from the wave's chunk ----------------
+            const uint64_t emptyMask = __ballot(rayIdx < 0);
+            const uint32_t need = __popcll(emptyMask);
+            if (wBeg == wEnd && !exhausted) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(a.cursor, a.chunk);
+                b = __builtin_amdgcn_readfirstlane(b);
+                wBeg = min(b, a.count);
+                wEnd = min(b + a.chunk, a.count);
+                exhausted = (b >= a.count) || (b + a.chunk < b);
+            }
+            const uint32_t take = min(need, wEnd - wBeg);
+            const uint32_t rank = laneRank(emptyMask);
+            if (rayIdx < 0 && rank < take) {
+                const uint32_t idx = wBeg + rank;
+                const float4 q0 = a.rays[size_t(idx) * 2 + 0];
+                const float4 q1 = a.rays[size_t(idx) * 2 + 1];
+                const bool valid = isfinite(q0.x) && isfinite(q0.y) && isfinite(q0.z) && isfinite(q0.w) &&
+                                   isfinite(q1.x) && isfinite(q1.y) && isfinite(q1.z) && !isnan(q1.w);
+                if (!valid) {   // defined as a miss with rgb = 0 (the reference leaves this undefined)
+                    a.results[idx] = make_float4(__uint_as_float(kInvalidTriangle), 0.0f, 0.0f, 0.0f);
+                } else {
+                    const float eps = 1e-10f;   // Kernels.h:149-157
+                    r.ox = q0.x; r.oy = q0.y; r.oz = q0.z; r.tNear = q0.w;
+                    r.dx = (fabsf(q1.x) < eps) ? copysignf(eps, q1.x) : q1.x;
+                    r.dy = (fabsf(q1.y) < eps) ? copysignf(eps, q1.y) : q1.y;
+                    r.dz = (fabsf(q1.z) < eps) ? copysignf(eps, q1.z) : q1.z;
+                    r.tFar = q1.w;
+                    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;    // Kernels.h:159-160
+                    r.ex = -r.ox * r.ix; r.ey = -r.oy * r.iy; r.ez = -r.oz * r.iz;
+                    r.hitIndex = -1; r.hitU = 0.0f; r.hitV = 0.0f;
+                    rayIdx = int(idx);
+                    node = 0x80000000u;     // root is always inner node 0 (Kernels.h:164)
+                    sp = 0;
+                }
+            }
+            wBeg += take;
+            if (exhausted && wBeg == wEnd && __ballot(rayIdx >= 0) == 0ull) break;
+            continue;
+        }
+
+        if (nLeaf >= a.leafMin || nInner == 0u) {
+            // ---------------- leaf step: one triangle pair per lane (Kernels.h:200-205) ----------------
+            if (int(node) >= int(kLeafBase)) {
+                const uint32_t cur = node & 0xFFFFFFu;
+                const uint32_t cnt = node >> 24;
+                r.tFar = pairIntersect(a.pairs, cur, r);
+                if (cnt > 1u) {
+                    node = ((cnt - 1u) << 24) | (cur + 1u);
+                } else if (sp == 0u) {
+                    node = 0u;
+                } else {
+                    --sp;
+                    node = (sp < uint32_t(LDS_LEVELS)) ? myLds[sp * kBlock] : mySpill[size_t(sp - LDS_LEVELS) * a.spillStride];
+                }
+            }
+        } else {
+            // ---------------- inner step: two slab tests, descend nearer, push farther (Kernels.h:170-199) ----------------
+            if (int(node) < 0) {
+                const float4* np = a.nodes + size_t(node & 0x7FFFFFFFu) * 4;
+                const uint2 kids = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(np) + 2);
+                const float4 d1 = np[1], d2 = np[2], d3 = np[3];
+                const float tRay = r.tFar;
+                const float tFirst = aabbIntersect(d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tNear, tRay);
+                const float tLast = aabbIntersect(d2.z, d2.w, d3.x, d3.y, d3.z, d3.w, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tNear, tRay);
+                const float firstDiff = tRay - tFirst, lastDiff = tRay - tLast;
+                if (firstDiff + lastDiff != 0.0f) {
+                    const bool lastNearer = tLast < tFirst;      // signbit(tLast - tFirst), Kernels.h:193
+                    if (fmaxf(tFirst, tLast) != tRay) {
+                        const uint32_t far = lastNearer ? kids.x : kids.y;
+                        if (sp < uint32_t(LDS_LEVELS)) myLds[sp * kBlock] = far; else mySpill[size_t(sp - LDS_LEVELS) * a.spillStride] = far;
+                        ++sp;
+                    }
+                    node = lastNearer ? kids.y : kids.x;
+                } else if (sp == 0u) {
+                    node = 0u;
+                } else {
+                    --sp;
+                    node = (sp < uint32_t(LDS_LEVELS)) ? myLds[sp * kBlock] : mySpill[size_t(sp - LDS_LEVELS) * a.spillStride];
+                }
+            }
+        }
+    }
+
+    // The last block to leave re-arms the cursor for the next launch on this lane (no host memset needed).
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t prev = atomicInc(a.cursor + 1, gridDim.x - 1);
+        if (prev == gridDim.x - 1) atomicExch(a.cursor, 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+
+thread_local char g_msg[512];
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+    if (e != hipSuccess) snprintf(g_msg, sizeof(g_msg), "racc_hip: %s: %s", what, hipGetErrorString(e));
+    else snprintf(g_msg, sizeof(g_msg), "racc_hip: %s", what);
+    racc_hip_set_error_(g_msg);
+    return code;
+}
+
+#define HIP_TRY(call, what)                                                      \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) return fail(RACC_HIP_ERR_DEVICE, what, e_);        \
+    } while (0)
+
+struct Lane {
+    hipStream_t stream = nullptr;
+    uint32_t* cursor = nullptr;          // 2 words, zero-initialised; the kernel re-arms it
+    uint32_t* spill = nullptr;
+    size_t spillWords = 0;
+    void* dRays = nullptr;               // staging for the host-buffer path
+    void* dResults = nullptr;
+    uint32_t capacity = 0;
+    std::vector<hipEvent_t> events;
+    racc_hip_launch_info info{};
+};
+
+}  // namespace
+
+struct racc_hip_ctx {
+    int device = 0;
+    int numCUs = 0;
+    racc_hip_options opts{};
+    Lane lanes[RACC_HIP_MAX_LANES];
+};
+
+struct racc_hip_scene {
+    float4* nodes = nullptr;
+    float4* pairs = nullptr;
+    uint32_t* remap = nullptr;
+    racc_hip_scene_info info{};
+};
+
+struct racc_hip_env {
+    float4* pixels = nullptr;
+    uint32_t width = 0, height = 0;
+};
+
+namespace {
+
+struct GpuNodeHost { uint32_t kind, parent, first, last; float box[12]; };
+
+// Walks the blob from the root: every child index / pair range must be in bounds and every inner node
+// reachable at most once (a DAG or cycle would make traversal unbounded).  Also measures the height.
+int validateScene(const GpuNodeHost* nodes, uint32_t nodeCount, uint32_t pairCount, uint32_t remapCount,
+                  racc_hip_scene_info& info) {
+    if (!nodeCount) return fail(RACC_HIP_ERR_LIMIT, "scene has no inner node (needs >= 3 triangles; root must be inner, Kernels.h:164)");
+    if (nodeCount >= 0x7FFFFFFFu || pairCount > (1u << 24)) return fail(RACC_HIP_ERR_LIMIT, "node/pair count exceeds the reference format (Scene.cpp:294-312)");
+    std::vector<uint8_t> seen(nodeCount, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> work;   // (node, depth)
+    work.emplace_back(0u, 1u);
+    seen[0] = 1;
+    uint32_t height = 0, maxLeaf = 0;
+    while (!work.empty()) {
+        const auto [n, depth] = work.back();
+        work.pop_back();
+        height = depth > height ? depth : height;
+        const uint32_t kids[2] = { nodes[n].first, nodes[n].last };
+        for (uint32_t c : kids) {
+            if (c & 0x80000000u) {
+                const uint32_t ci = c & 0x7FFFFFFFu;
+                if (ci >= nodeCount) return fail(RACC_HIP_ERR_INVALID, "scene blob: child index out of range");
+                if (seen[ci]) return fail(RACC_HIP_ERR_INVALID, "scene blob: inner node referenced twice (not a tree)");
+                seen[ci] = 1;
+                work.emplace_back(ci, depth + 1);
+            } else {
+                const uint32_t first = c & 0xFFFFFFu, cnt = c >> 24;
+                if (cnt == 0) return fail(RACC_HIP_ERR_INVALID, "scene blob: leaf with zero pairs");
+                if (first + cnt > pairCount) return fail(RACC_HIP_ERR_INVALID, "scene blob: leaf pair range out of bounds");
+                if ((first + cnt) * 2ull > remapCount) return fail(RACC_HIP_ERR_INVALID, "scene blob: remap shorter than the pairs it indexes");
+                maxLeaf = cnt > maxLeaf ? cnt : maxLeaf;
+            }
+        }
+    }
+    info.inner_height = height;
+    info.max_leaf_pairs = maxLeaf;
+    // A push happens at most once per inner node on the current root path.
+    info.spill_levels = height > uint32_t(kLdsLevels) ? height - uint32_t(kLdsLevels) : 0u;
+    return RACC_HIP_OK;
+}
+
+int ensureSpill(racc_hip_ctx* ctx, Lane& lane, uint32_t gridThreads, uint32_t levels) {
+    const size_t words = size_t(gridThreads) * (levels ? levels : 1u);
+    if (lane.spillWords >= words) return RACC_HIP_OK;
+    (void)ctx;
+    if (lane.spill) { HIP_TRY(hipFree(lane.spill), "hipFree(spill)"); lane.spill = nullptr; lane.spillWords = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&lane.spill), words * sizeof(uint32_t)), "hipMalloc(spill)");
+    lane.spillWords = words;
+    return RACC_HIP_OK;
+}
+
+uint32_t optOr(uint32_t v, uint32_t dflt) { return v ? v : dflt; }
+
+int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc_hip_scene* scene, const racc_hip_env* env,
+                   const void* dRays, void* dResults, uint32_t count) {
+    if (!count) return RACC_HIP_OK;
+    const uint32_t wavesPerSimd = optOr(ctx->opts.waves_per_simd, 8u);
+    const uint32_t chunk = optOr(ctx->opts.chunk, 64u);
+    uint32_t blocks = uint32_t(ctx->numCUs) * wavesPerSimd;                      // 4 waves per block = 1 wave per SIMD
+    const uint32_t blocksNeeded = (count + kBlock - 1) / kBlock;
+    if (blocks > blocksNeeded) blocks = blocksNeeded;
+    const uint32_t gridThreads = blocks * kBlock;
+    if (int rc = ensureSpill(ctx, lane, uint32_t(ctx->numCUs) * 8u * kBlock, scene->info.spill_levels)) return rc;
+
+    TraverseArgs a;
+    a.rays = static_cast<const float4*>(dRays);
+    a.results = static_cast<float4*>(dResults);
+    a.count = count;
+    a.nodes = scene->nodes; a.pairs = scene->pairs; a.remap = scene->remap;
+    a.env = env ? env->pixels : nullptr;
+    a.envW = env ? env->width : 0; a.envH = env ? env->height : 0;
+    a.cursor = lane.cursor;
+    a.spill = lane.spill;
+    a.spillStride = gridThreads;
+    a.chunk = chunk;
+    a.refillMin = optOr(ctx->opts.refill_min, 16u);
+    a.leafMin = optOr(ctx->opts.leaf_min, 24u);
+    hipLaunchKernelGGL(traverseKernel<kLdsLevels>, dim3(blocks), dim3(kBlock), 0, stream, a);
+    HIP_TRY(hipGetLastError(), "launch traverseKernel");
+    lane.info.grid_blocks = blocks;
+    lane.info.block_threads = kBlock;
+    lane.info.lds_bytes_per_block = kLdsLevels * kBlock * 4;
+    lane.info.waves_per_simd = wavesPerSimd;
+    return RACC_HIP_OK;
+}
+
+int checkLane(racc_hip_ctx* ctx, uint32_t lane) {
+    if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
+    if (lane >= ctx->opts.lanes) return fail(RACC_HIP_ERR_INVALID, "lane out of range");
+    return RACC_HIP_OK;
+}
+
+int ensureStaging(Lane& lane, uint32_t count) {
+    if (lane.capacity >= count) return RACC_HIP_OK;
+    if (lane.dRays) { HIP_TRY(hipFree(lane.dRays), "hipFree(staging rays)"); lane.dRays = nullptr; }
+    if (lane.dResults) { HIP_TRY(hipFree(lane.dResults), "hipFree(staging results)"); lane.dResults = nullptr; }
+    lane.capacity = 0;
+    uint32_t cap = 32768;
+    while (cap < count) cap <<= 1;
+    HIP_TRY(hipMalloc(&lane.dRays, size_t(cap) * 32), "hipMalloc(staging rays)");
+    HIP_TRY(hipMalloc(&lane.dResults, size_t(cap) * 16), "hipMalloc(staging results)");
+    lane.capacity = cap;
+    return RACC_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* racc_hip_version(void) { return "racc-hip 0.1 (gfx950)"; }
+
+int racc_hip_device_count(int* count) {
+    if (!count) return fail(RACC_HIP_ERR_INVALID, "count is NULL");
+    *count = 0;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(RACC_HIP_ERR_NO_DEVICE, "hipGetDeviceCount", e);
+    *count = n;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out) {
+    if (!out) return fail(RACC_HIP_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(RACC_HIP_ERR_NO_DEVICE, "no HIP device (there is no CPU fallback)", e);
+    if (device < 0 || device >= n) return fail(RACC_HIP_ERR_INVALID, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_msg, sizeof(g_msg), "device %d is %s; this engine is built for gfx950 only", device, prop.gcnArchName);
+        return fail(RACC_HIP_ERR_NO_DEVICE, g_msg);
+    }
+    HIP_TRY(hipSetDevice(device), "hipSetDevice");
+    racc_hip_ctx* ctx = new (std::nothrow) racc_hip_ctx();
+    if (!ctx) return fail(RACC_HIP_ERR_NOMEM, "out of host memory");
+    ctx->device = device;
+    ctx->numCUs = prop.multiProcessorCount;
+    if (opts) {
+        const size_t n_copy = opts->struct_size && opts->struct_size < sizeof(racc_hip_options) ? opts->struct_size : sizeof(racc_hip_options);
+        memcpy(&ctx->opts, opts, n_copy);
+    }
+    ctx->opts.struct_size = sizeof(racc_hip_options);
+    if (!ctx->opts.lanes) ctx->opts.lanes = 4;                       // RayAccelerator.cpp:436
+    if (ctx->opts.lanes > RACC_HIP_MAX_LANES) ctx->opts.lanes = RACC_HIP_MAX_LANES;
+    if (ctx->opts.waves_per_simd > 8) ctx->opts.waves_per_simd = 8;
+    if (ctx->opts.refill_min > 64) ctx->opts.refill_min = 64;
+    if (ctx->opts.leaf_min > 64) ctx->opts.leaf_min = 64;
+    for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
+        Lane& l = ctx->lanes[i];
+        hipError_t e1 = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+        hipError_t e2 = e1 == hipSuccess ? hipMalloc(reinterpret_cast<void**>(&l.cursor), 64) : e1;
+        hipError_t e3 = e2 == hipSuccess ? hipMemset(l.cursor, 0, 64) : e2;
+        if (e3 != hipSuccess) { racc_hip_destroy(ctx); return fail(RACC_HIP_ERR_DEVICE, "lane setup", e3); }
+    }
+    *out = ctx;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_destroy(racc_hip_ctx* ctx) {
+    if (!ctx) return RACC_HIP_OK;
+    hipSetDevice(ctx->device);
+    for (Lane& l : ctx->lanes) {
+        if (l.stream) hipStreamSynchronize(l.stream);
+        for (hipEvent_t ev : l.events) hipEventDestroy(ev);
+        if (l.cursor) hipFree(l.cursor);
+        if (l.spill) hipFree(l.spill);
+        if (l.dRays) hipFree(l.dRays);
+        if (l.dResults) hipFree(l.dResults);
+        if (l.stream) hipStreamDestroy(l.stream);
+    }
+    delete ctx;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_scene_upload(racc_hip_ctx* ctx, const void* nodes64, uint32_t node_count,
+                          const void* pairs48, uint32_t pair_count,
+                          const uint32_t* remap, uint32_t remap_count, racc_hip_scene** out) {
+    if (!ctx || !out) return fail(RACC_HIP_ERR_INVALID, "ctx/out is NULL");
+    *out = nullptr;
+    if (!nodes64 || !pairs48 || !remap) return fail(RACC_HIP_ERR_INVALID, "scene blob pointer is NULL");
+    racc_hip_scene_info info{};
+    if (int rc = validateScene(static_cast<const GpuNodeHost*>(nodes64), node_count, pair_count, remap_count, info)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    racc_hip_scene* s = new (std::nothrow) racc_hip_scene();
+    if (!s) return fail(RACC_HIP_ERR_NOMEM, "out of host memory");
+    const size_t nb = size_t(node_count) * 64, pb = size_t(pair_count) * 48, rb = size_t(remap_count) * 4;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->nodes), nb);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->pairs), pb);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->remap), rb ? rb : 4);
+    if (e == hipSuccess) e = hipMemcpy(s->nodes, nodes64, nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->pairs, pairs48, pb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && rb) e = hipMemcpy(s->remap, remap, rb, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { racc_hip_scene_free(ctx, s); return fail(RACC_HIP_ERR_DEVICE, "scene upload", e); }
+    info.node_count = node_count; info.pair_count = pair_count; info.remap_count = remap_count;
+    info.device_bytes = nb + pb + rb;
+    s->info = info;
+    *out = s;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_scene_free(racc_hip_ctx* ctx, racc_hip_scene* s) {
+    if (!s) return RACC_HIP_OK;
+    if (ctx) hipSetDevice(ctx->device);
+    if (s->nodes) hipFree(s->nodes);
+    if (s->pairs) hipFree(s->pairs);
+    if (s->remap) hipFree(s->remap);
+    delete s;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_scene_get_info(const racc_hip_scene* scene, racc_hip_scene_info* info) {
+    if (!scene || !info) return fail(RACC_HIP_ERR_INVALID, "scene/info is NULL");
+    *info = scene->info;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_env_upload(racc_hip_ctx* ctx, const float* rgba, uint32_t width, uint32_t height, racc_hip_env** out) {
+    if (!ctx || !out) return fail(RACC_HIP_ERR_INVALID, "ctx/out is NULL");
+    *out = nullptr;
+    if (!rgba || !width || !height) return fail(RACC_HIP_ERR_INVALID, "environment image is empty");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    racc_hip_env* env = new (std::nothrow) racc_hip_env();
+    if (!env) return fail(RACC_HIP_ERR_NOMEM, "out of host memory");
+    const size_t bytes = size_t(width) * height * 16;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&env->pixels), bytes);
+    if (e == hipSuccess) e = hipMemcpy(env->pixels, rgba, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { racc_hip_env_free(ctx, env); return fail(RACC_HIP_ERR_DEVICE, "environment upload", e); }
+    env->width = width; env->height = height;
+    *out = env;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_env_free(racc_hip_ctx* ctx, racc_hip_env* env) {
+    if (!env) return RACC_HIP_OK;
+    if (ctx) hipSetDevice(ctx->device);
+    if (env->pixels) hipFree(env->pixels);
+    delete env;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_register_stream(racc_hip_ctx* ctx, void* rays, void* results, uint32_t capacity) {
+    if (!ctx || !rays || !results || !capacity) return fail(RACC_HIP_ERR_INVALID, "register_stream: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    HIP_TRY(hipHostRegister(rays, size_t(capacity) * 32, hipHostRegisterDefault), "hipHostRegister(rays)");
+    hipError_t e = hipHostRegister(results, size_t(capacity) * 16, hipHostRegisterDefault);
+    if (e != hipSuccess) { hipHostUnregister(rays); return fail(RACC_HIP_ERR_DEVICE, "hipHostRegister(results)", e); }
+    return RACC_HIP_OK;
+}
+
+int racc_hip_unregister_stream(racc_hip_ctx* ctx, void* rays, void* results) {
+    if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    if (rays) HIP_TRY(hipHostUnregister(rays), "hipHostUnregister(rays)");
+    if (results) HIP_TRY(hipHostUnregister(results), "hipHostUnregister(results)");
+    return RACC_HIP_OK;
+}
+
+int racc_hip_intersect_async(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
+                             const void* rays, void* results, uint32_t count, uint32_t lane) {
+    if (int rc = checkLane(ctx, lane)) return rc;
+    if (!scene) return fail(RACC_HIP_ERR_INVALID, "scene is NULL");
+    if (!count) return RACC_HIP_OK;
+    if (!rays || !results) return fail(RACC_HIP_ERR_INVALID, "rays/results is NULL");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    Lane& l = ctx->lanes[lane];
+    HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");     // staging buffers are reused per lane
+    if (int rc = ensureStaging(l, count)) return rc;
+    HIP_TRY(hipMemcpyAsync(l.dRays, rays, size_t(count) * 32, hipMemcpyHostToDevice, l.stream), "H2D rays");
+    if (int rc = launchTraverse(ctx, l, l.stream, scene, env, l.dRays, l.dResults, count)) return rc;
+    HIP_TRY(hipMemcpyAsync(results, l.dResults, size_t(count) * 16, hipMemcpyDeviceToHost, l.stream), "D2H results");
+    return RACC_HIP_OK;
+}
+
+int racc_hip_wait(racc_hip_ctx* ctx, uint32_t lane) {
+    if (int rc = checkLane(ctx, lane)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    HIP_TRY(hipStreamSynchronize(ctx->lanes[lane].stream), "hipStreamSynchronize");
+    return RACC_HIP_OK;
+}
+
+int racc_hip_intersect(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
+                       const void* rays, void* results, uint32_t count, uint32_t lane) {
+    if (int rc = racc_hip_intersect_async(ctx, scene, env, rays, results, count, lane)) return rc;
+    return racc_hip_wait(ctx, lane);
+}
+
+int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
+                              const void* d_rays, void* d_results, uint32_t count, uint32_t lane, void* stream) {
+    if (int rc = checkLane(ctx, lane)) return rc;
+    if (!scene) return fail(RACC_HIP_ERR_INVALID, "scene is NULL");
+    if (!count) return RACC_HIP_OK;
+    if (!d_rays || !d_results) return fail(RACC_HIP_ERR_INVALID, "d_rays/d_results is NULL");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    Lane& l = ctx->lanes[lane];
+    return launchTraverse(ctx, l, stream ? static_cast<hipStream_t>(stream) : l.stream, scene, env, d_rays, d_results, count);
+}
+
+int racc_hip_intersect_device_timed(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
+                                    const void* d_rays, void* d_results, uint32_t count,
+                                    uint32_t lane, uint32_t iters, float* ms) {
+    if (int rc = checkLane(ctx, lane)) return rc;
+    if (!scene || !ms || !iters) return fail(RACC_HIP_ERR_INVALID, "timed: bad argument");
+    if (!d_rays || !d_results || !count) return fail(RACC_HIP_ERR_INVALID, "timed: empty batch");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    Lane& l = ctx->lanes[lane];
+    while (l.events.size() < size_t(iters) * 2) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev), "hipEventCreate");
+        l.events.push_back(ev);
+    }
+    for (uint32_t i = 0; i < iters; ++i) {
+        HIP_TRY(hipEventRecord(l.events[2 * i], l.stream), "hipEventRecord");
+        if (int rc = launchTraverse(ctx, l, l.stream, scene, env, d_rays, d_results, count)) return rc;
+        HIP_TRY(hipEventRecord(l.events[2 * i + 1], l.stream), "hipEventRecord");
+    }
+    HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
+    for (uint32_t i = 0; i < iters; ++i)
+        HIP_TRY(hipEventElapsedTime(&ms[i], l.events[2 * i], l.events[2 * i + 1]), "hipEventElapsedTime");
+    l.info.last_kernel_ms = ms[iters - 1];
+    return RACC_HIP_OK;
+}
+
+int racc_hip_get_launch_info(racc_hip_ctx* ctx, uint32_t lane, racc_hip_launch_info* info) {
+    if (int rc = checkLane(ctx, lane)) return rc;
+    if (!info) return fail(RACC_HIP_ERR_INVALID, "info is NULL");
+    *info = ctx->lanes[lane].info;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_malloc(racc_hip_ctx* ctx, uint64_t bytes, void** d_ptr) {
+    if (!ctx || !d_ptr) return fail(RACC_HIP_ERR_INVALID, "malloc: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1), "hipMalloc");
+    return RACC_HIP_OK;
+}
+
+int racc_hip_free(racc_hip_ctx* ctx, void* d_ptr) {
+    if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    if (d_ptr) HIP_TRY(hipFree(d_ptr), "hipFree");
+    return RACC_HIP_OK;
+}
+
+int racc_hip_memcpy_h2d(racc_hip_ctx* ctx, void* d_dst, const void* src, uint64_t bytes) {
+    if (!ctx || !d_dst || !src) return fail(RACC_HIP_ERR_INVALID, "memcpy_h2d: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    HIP_TRY(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D");
+    return RACC_HIP_OK;
+}
+
+int racc_hip_memcpy_d2h(racc_hip_ctx* ctx, void* dst, const void* d_src, uint64_t bytes) {
+    if (!ctx || !dst || !d_src) return fail(RACC_HIP_ERR_INVALID, "memcpy_d2h: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H");
+    return RACC_HIP_OK;
+}
+
+int racc_hip_synchronize(racc_hip_ctx* ctx) {
+    if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    return RACC_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,303 @@
+"""ctypes binding of include/racc_hip.h, shaped like the reference's `racc::` interface.
+
+Python is only the test/bench harness language here; the product is
+rayaccel_amd/libracc_hip.so (hand-written HIP for gfx950 behind a C-ABI).  The
+names below mirror RayAccelerator/RayAccelerator.h:95-115 for the intersect-batch
+path: `Context` ≙ racc::createContext, `Context.create_scene` ≙ racc::createScene,
+`Context.create_environment` ≙ racc::createEnvironment, `Context.intersect` ≙ one
+gpuWorkerThread dispatch (RayAccelerator.cpp:378-404).
+
+There is NO CPU fallback: if the library is missing, fails to load, or finds no
+gfx950 device, every GPU entry point raises RaccError.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .synth import RAY_DTYPE, RESULT_DTYPE, INVALID_TRIANGLE  # noqa: F401  (re-exported)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libracc_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+BVH2_NODE_DTYPE = np.dtype([("kind", "<u4"), ("parent", "<u4"), ("first", "<u4"), ("last", "<u4"),
+                            ("bbMin", "<f4", 3), ("dummy0", "<u4"), ("bbMax", "<f4", 3), ("dummy1", "<u4")])
+GPU_NODE_DTYPE = np.dtype([("kind", "<u4"), ("parent", "<u4"), ("first", "<u4"), ("last", "<u4"),
+                           ("leftMin", "<f4", 3), ("leftMax", "<f4", 3), ("rightMin", "<f4", 3), ("rightMax", "<f4", 3)])
+PAIR_DTYPE = np.dtype([("e1", "<f4", 3), ("e3x", "<f4"), ("e2", "<f4", 3), ("e3y", "<f4"), ("p0", "<f4", 3), ("e3z", "<f4")])
+
+
+class RaccError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("racc_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+class Options(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("lanes", C.c_uint32), ("waves_per_simd", C.c_uint32),
+                ("kernel_variant", C.c_uint32), ("refill_min", C.c_uint32), ("leaf_min", C.c_uint32),
+                ("chunk", C.c_uint32), ("reserved", C.c_uint32 * 9)]
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("node_count", C.c_uint32), ("pair_count", C.c_uint32), ("remap_count", C.c_uint32),
+                ("inner_height", C.c_uint32), ("max_leaf_pairs", C.c_uint32), ("spill_levels", C.c_uint32),
+                ("device_bytes", C.c_uint64)]
+
+
+class LaunchInfo(C.Structure):
+    _fields_ = [("grid_blocks", C.c_uint32), ("block_threads", C.c_uint32), ("lds_bytes_per_block", C.c_uint32),
+                ("waves_per_simd", C.c_uint32), ("last_kernel_ms", C.c_float)]
+
+
+# Every symbol include/racc_hip.h declares, with its ctypes signature.
+_vp, _u32, _u64, _i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+_P = C.POINTER
+ABI = {
+    "racc_hip_last_error": (C.c_char_p, []),
+    "racc_hip_version": (C.c_char_p, []),
+    "racc_hip_device_count": (_i, [_P(_i)]),
+    "racc_hip_create": (_i, [_i, _P(Options), _P(_vp)]),
+    "racc_hip_destroy": (_i, [_vp]),
+    "racc_hip_scene_upload": (_i, [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _P(_vp)]),
+    "racc_hip_scene_free": (_i, [_vp, _vp]),
+    "racc_hip_scene_get_info": (_i, [_vp, _P(SceneInfo)]),
+    "racc_hip_env_upload": (_i, [_vp, _vp, _u32, _u32, _P(_vp)]),
+    "racc_hip_env_free": (_i, [_vp, _vp]),
+    "racc_hip_register_stream": (_i, [_vp, _vp, _vp, _u32]),
+    "racc_hip_unregister_stream": (_i, [_vp, _vp, _vp]),
+    "racc_hip_intersect": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32]),
+    "racc_hip_intersect_async": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32]),
+    "racc_hip_wait": (_i, [_vp, _u32]),
+    "racc_hip_intersect_device": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp]),
+    "racc_hip_intersect_device_timed": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _P(C.c_float)]),
+    "racc_hip_get_launch_info": (_i, [_vp, _u32, _P(LaunchInfo)]),
+    "racc_hip_malloc": (_i, [_vp, _u64, _P(_vp)]),
+    "racc_hip_free": (_i, [_vp, _vp]),
+    "racc_hip_memcpy_h2d": (_i, [_vp, _vp, _vp, _u64]),
+    "racc_hip_memcpy_d2h": (_i, [_vp, _vp, _vp, _u64]),
+    "racc_hip_synchronize": (_i, [_vp]),
+    "racc_host_scene_build": (_i, [_vp, _u32, _vp, _u32, _P(_vp)]),
+    "racc_host_scene_free": (_i, [_vp]),
+    "racc_host_scene_blobs": (_i, [_vp, _P(_vp), _P(_u32), _P(_vp), _P(_u32), _P(_u32), _P(_vp), _P(_u32)]),
+    "racc_host_scene_bvh2": (_i, [_vp, _P(_vp), _P(_u32), _P(_vp), _P(_u32)]),
+}
+
+_lib = None
+
+
+def build_library(force=False):
+    """Compile libracc_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("racc_hip.hip", "scene_build.cpp", "Makefile")]
+    srcs.append(os.path.join(_HERE, "..", "include", "racc_hip.h"))
+    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", CSRC])
+    return LIB_PATH
+
+
+def load_library():
+    """dlopen libracc_hip.so and bind every ABI symbol.  Raises RaccError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RaccError(-3, "libracc_hip.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise RaccError(-3, "cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)  # AttributeError here means the header and the .so disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RaccError(rc, load_library().racc_hip_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _as_verts4(vertices):
+    v = np.asarray(vertices, dtype=np.float32)
+    if v.ndim != 2 or v.shape[1] not in (3, 4):
+        raise ValueError("vertices must be [V,3] or [V,4] float32")
+    if v.shape[1] == 3:
+        v = np.concatenate([v, np.zeros((len(v), 1), np.float32)], 1)
+    out = np.empty((len(v) + 4, 4), np.float32)  # over-allocate to find a 16-byte aligned start
+    off = (-out.ctypes.data % 16) // 4
+    flat = out.reshape(-1)[off: off + v.size].reshape(v.shape)
+    flat[...] = v
+    return flat
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load_library().racc_hip_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class HostScene:
+    """Host-side build product ≙ the GPU branch of racc::createScene (Scene.cpp:216-339)."""
+
+    def __init__(self, vertices, indices):
+        lib = load_library()
+        v = _as_verts4(vertices)
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        h = C.c_void_p()
+        _check(lib.racc_host_scene_build(_ptr(v), len(v), _ptr(idx), idx.size, C.byref(h)))
+        try:
+            pn, pp, pr = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            nn, npad, npair, nr = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+            _check(lib.racc_host_scene_blobs(h, C.byref(pn), C.byref(nn), C.byref(pp), C.byref(npad), C.byref(npair), C.byref(pr), C.byref(nr)))
+            self.nodes = np.ctypeslib.as_array(C.cast(pn, _P(C.c_uint8)), (nn.value * 64,)).view(GPU_NODE_DTYPE).copy()
+            self.pairs = np.ctypeslib.as_array(C.cast(pp, _P(C.c_uint8)), (npad.value * 48,)).view(PAIR_DTYPE).copy()
+            self.remap = np.ctypeslib.as_array(C.cast(pr, _P(C.c_uint32)), (nr.value,)).copy() if nr.value else np.zeros(0, np.uint32)
+            self.pair_count = npair.value
+            pb, pt = C.c_void_p(), C.c_void_p()
+            nb, nt = C.c_uint32(), C.c_uint32()
+            _check(lib.racc_host_scene_bvh2(h, C.byref(pb), C.byref(nb), C.byref(pt), C.byref(nt)))
+            self.bvh_nodes = np.ctypeslib.as_array(C.cast(pb, _P(C.c_uint8)), (nb.value * 48,)).view(BVH2_NODE_DTYPE).copy()
+            self.bvh_triangles = np.ctypeslib.as_array(C.cast(pt, _P(C.c_uint32)), (nt.value,)).copy()
+        finally:
+            lib.racc_host_scene_free(h)
+
+    def blobs(self):
+        return dict(nodes=self.nodes, pairs=self.pairs, remap=self.remap, pair_count=self.pair_count)
+
+
+class Scene:
+    def __init__(self, ctx, handle):
+        self._ctx, self._h = ctx, handle
+        info = SceneInfo()
+        _check(load_library().racc_hip_scene_get_info(handle, C.byref(info)))
+        self.info = {f: getattr(info, f) for f, _ in SceneInfo._fields_}
+
+    def destroy(self):
+        if self._h:
+            load_library().racc_hip_scene_free(self._ctx._h, self._h)
+            self._h = None
+
+
+class Environment:
+    def __init__(self, ctx, handle, width, height):
+        self._ctx, self._h, self.width, self.height = ctx, handle, width, height
+
+    def destroy(self):
+        if self._h:
+            load_library().racc_hip_env_free(self._ctx._h, self._h)
+            self._h = None
+
+
+class DeviceBuffer:
+    """Device allocation owned by the engine (for hosts without torch)."""
+
+    def __init__(self, ctx, nbytes):
+        self._ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        _check(load_library().racc_hip_malloc(ctx._h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array)
+        assert a.nbytes <= self.nbytes
+        _check(load_library().racc_hip_memcpy_h2d(self._ctx._h, self.ptr, _ptr(a), a.nbytes))
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype)
+        assert out.nbytes <= self.nbytes
+        _check(load_library().racc_hip_memcpy_d2h(self._ctx._h, _ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            load_library().racc_hip_free(self._ctx._h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """≙ racc::Context for the GPU intersect path; one per (process, GPU)."""
+
+    def __init__(self, device=0, lanes=0, waves_per_simd=0, refill_min=0, leaf_min=0, chunk=0, kernel_variant=0):
+        lib = load_library()
+        o = Options()
+        o.struct_size = C.sizeof(Options)
+        o.lanes, o.waves_per_simd, o.refill_min, o.leaf_min, o.chunk, o.kernel_variant = lanes, waves_per_simd, refill_min, leaf_min, chunk, kernel_variant
+        h = C.c_void_p()
+        _check(lib.racc_hip_create(device, C.byref(o), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def destroy(self):
+        if self._h:
+            load_library().racc_hip_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.destroy()
+
+    # -- scene / environment ---------------------------------------------------------------
+    def upload_scene(self, nodes, pairs, remap):
+        """Reference-format blobs in (≙ Scene.cpp:342-346)."""
+        nodes = np.ascontiguousarray(nodes)
+        pairs = np.ascontiguousarray(pairs)
+        remap = np.ascontiguousarray(remap, dtype=np.uint32)
+        assert nodes.dtype.itemsize == 64 and pairs.dtype.itemsize == 48
+        h = C.c_void_p()
+        _check(load_library().racc_hip_scene_upload(self._h, _ptr(nodes), len(nodes), _ptr(pairs), len(pairs), _ptr(remap), len(remap), C.byref(h)))
+        return Scene(self, h)
+
+    def create_scene(self, vertices, indices):
+        """≙ racc::createScene (RayAccelerator.h:107): host build, then upload."""
+        hs = HostScene(vertices, indices)
+        return self.upload_scene(hs.nodes, hs.pairs, hs.remap)
+
+    def create_environment(self, colors):
+        """≙ racc::createEnvironment (RayAccelerator.h:111); colors [H,W,4] float32."""
+        c = np.ascontiguousarray(colors, dtype=np.float32)
+        h = C.c_void_p()
+        _check(load_library().racc_hip_env_upload(self._h, _ptr(c), c.shape[1], c.shape[0], C.byref(h)))
+        return Environment(self, h, c.shape[1], c.shape[0])
+
+    # -- intersect -------------------------------------------------------------------------
+    def intersect(self, scene, env, rays, results=None, lane=0):
+        """Host Ray[N] in, host Result[N] out, blocking (≙ enqueue + clFinish)."""
+        rays = np.ascontiguousarray(rays)
+        assert rays.dtype.itemsize == 32
+        if results is None:
+            results = np.zeros(len(rays), RESULT_DTYPE)
+        _check(load_library().racc_hip_intersect(self._h, scene._h, env._h if env else None, _ptr(rays), _ptr(results), len(rays), lane))
+        return results
+
+    def intersect_device(self, scene, env, d_rays, d_results, count, lane=0, stream=None):
+        _check(load_library().racc_hip_intersect_device(self._h, scene._h, env._h if env else None, d_rays, d_results, count, lane, stream))
+
+    def intersect_device_timed(self, scene, env, d_rays, d_results, count, iters, lane=0):
+        ms = (C.c_float * iters)()
+        _check(load_library().racc_hip_intersect_device_timed(self._h, scene._h, env._h if env else None, d_rays, d_results, count, lane, iters, ms))
+        return list(ms)
+
+    def wait(self, lane=0):
+        _check(load_library().racc_hip_wait(self._h, lane))
+
+    def synchronize(self):
+        _check(load_library().racc_hip_synchronize(self._h))
+
+    def launch_info(self, lane=0):
+        info = LaunchInfo()
+        _check(load_library().racc_hip_get_launch_info(self._h, lane, C.byref(info)))
+        return {f: getattr(info, f) for f, _ in LaunchInfo._fields_}
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
