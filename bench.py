@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Headline benchmark: Mrays/s of the intersect-batch hot path on MI355X.
+
+A "step" is one pass of the path over one batch: 1,048,576 first-bounce diffuse
+(incoherent) rays on the battlefield-synth stand-in scene per GPU (BASELINE.json
+configs[2]; at N GPUs every rank traces its own 1M-ray batch = configs[3]'s 8M rays at
+N=8, weak scaling, no data-path collective — rays never interact).  Inputs are resident
+in HBM before the timed region.  Output: ONE JSON line on rank 0 (see README/DESIGN.md).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_MEASURED_GBS = 6290.0      # same guide: float4-copy ceiling
+RAYS_PER_BATCH = 1 << 20
+KERNEL_NAME = "traverseKernel"
+
+
+def _committed_traffic():
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (or None)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
+    ap.add_argument("--grid", type=int, default=700, help="height-field resolution of battlefield-synth (700 = full)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import numpy as np
+    import torch                      # first: the engine then shares torch's HIP runtime in this process
+    import torch.distributed as dist
+
+    import rayaccel_amd as ra
+    from rayaccel_amd import synth
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- inputs (synthetic stand-in: the reference's battlefield.bin is unavailable) ----------
+    full = args.grid == 700
+    sc = synth.battlefield_synth() if full else synth.battlefield_synth(grid=args.grid, boxes=args.grid * 6, quads=args.grid * 28)
+    host = ra.HostScene(sc["vertices"], sc["indices"])
+    ctx = ra.Context(device=local_rank)
+    scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
+    env = ctx.create_environment(sc["env"])
+
+    primary, _ = synth.primary_rays(sc["camera"], 1024, 1024)
+    primary_hits = ctx.intersect(scene, env, primary)                       # GPU path, host buffers
+    bounce = synth.diffuse_bounce_rays(sc, primary, primary_hits, RAYS_PER_BATCH, first_sample=rank)
+    n = len(bounce)
+
+    d_rays = torch.from_numpy(bounce.view(np.float32).reshape(n, 8).copy()).cuda()
+    d_out = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+
+    def run(iters, rays_t=d_rays, out_t=d_out):
+        return ctx.intersect_device_timed(scene, env, rays_t.data_ptr(), out_t.data_ptr(), rays_t.shape[0], iters)
+
+    if args.warmup:
+        run(args.warmup)
+
+    # ---- timed region: exactly K steps, barrier + device sync on both sides --------------------
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = run(args.steps)          # K back-to-back launches, a HIP event pair around each, on the launch stream
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    value = world * n * args.steps / elapsed / 1e6
+    launch = ctx.launch_info()
+
+    # ---- optional extras, all outside the timed region ------------------------------------------
+    extras = {}
+    if world > 1:   # RCCL all-gather of the Result shards over xGMI (only needed by a GPU-side consumer)
+        gathered = torch.empty((world * n, 4), dtype=torch.float32, device="cuda")
+        dist.all_gather_into_tensor(gathered, d_out)
+        torch.cuda.synchronize(); barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dist.all_gather_into_tensor(gathered, d_out)
+        torch.cuda.synchronize()
+        extras["allgather_results_ms"] = round((time.perf_counter() - t1) / 5 * 1e3, 4)
+        extras["allgather_bytes"] = int(gathered.numel() * 4)
+    if rank == 0:
+        d_prim = torch.from_numpy(primary.view(np.float32).reshape(len(primary), 8).copy()).cuda()
+        d_prim_out = torch.zeros((len(primary), 4), dtype=torch.float32, device="cuda")
+        run(2, d_prim, d_prim_out)
+        pm = float(np.median(run(10, d_prim, d_prim_out)))
+        extras["coherent_1M"] = {"ms_per_step": round(pm, 4), "mrays_per_s": round(len(primary) / pm / 1e3, 1)}
+        # PCIe-inclusive rate of the host-buffer entry point (never `value`)
+        res_host = np.zeros(n, ra.RESULT_DTYPE)
+        ctx.intersect(scene, env, bounce, res_host)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ctx.intersect(scene, env, bounce, res_host)
+        extras["host_buffers_pcie_inclusive_mrays_per_s"] = round(3 * n / (time.perf_counter() - t1) / 1e6, 1)
+
+    # ---- roofline + CPU baseline (rank 0) --------------------------------------------------------
+    roofline, cpu_baseline = None, None
+    if rank == 0:
+        avg_kernel_ms = float(np.mean(kernel_ms))
+        alg_bytes, src = None, None
+        if not args.no_cpu_baseline:
+            from oracle import oracle            # checker / CPU leg only; never on the product path
+            blobs = host.blobs()
+            ref, nv, npairs, _ = oracle.traverse(blobs, bounce, env=sc["env"], counters=True)
+            alg_bytes, src = oracle.algorithmic_bytes(ref, nv, npairs), "oracle counters, live"
+            got = d_out.cpu().numpy().view(ra.RESULT_DTYPE).reshape(-1)
+            if not np.array_equal(got["triangle"], ref["triangle"]):
+                sys.exit("bench: GPU results differ from the oracle — refusing to report a number")
+            threads = os.cpu_count() or 1
+            times = []
+            oracle.traverse(blobs, bounce, env=sc["env"], threads=threads)
+            for _ in range(5):
+                t1 = time.perf_counter()
+                oracle.traverse(blobs, bounce, env=sc["env"], threads=threads)
+                times.append(time.perf_counter() - t1)
+            cpu_baseline = {"value": round(n / float(np.median(times)) / 1e6, 2), "unit": "Mrays/s", "cores": threads,
+                            "kind": "port",
+                            "sample": "the full 1,048,576-ray diffuse batch, median of 5 passes, %d pthreads x 1024-ray slices; "
+                                      "CPU BVH2 restatement standing in for Embree (Embree unavailable)" % threads}
+        else:
+            try:
+                with open(os.path.join(ROOT, "tests", "golden", "algorithmic_bytes.json")) as f:
+                    alg_bytes = json.load(f)["diffuse_1M_sample0"]["bytes"] if full else None
+                    src = "tests/golden/algorithmic_bytes.json"
+            except (OSError, KeyError, ValueError):
+                pass
+        if alg_bytes:
+            achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+            traffic = _committed_traffic()
+            roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
+                        "kernel": KERNEL_NAME, "kernel_ms_avg": round(avg_kernel_ms, 4),
+                        "algorithmic_bytes_per_launch": int(alg_bytes), "algorithmic_bytes_source": src,
+                        "frac_of_measured_6290": round(achieved / HBM_MEASURED_GBS, 4)}
+
+        line = {
+            "metric": "Mrays/s", "value": round(value, 1), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "battlefield-synth (stand-in; reference scene unavailable), %d triangles, "
+                                   "1M 1st-bounce diffuse rays per GPU (BASELINE configs[2]/[3])" % len(sc["indices"]),
+                       "rays_per_gpu": n, "scene": sc["name"], "parallelism": "rays sharded x%d, scene replicated" % world,
+                       "grid_blocks": launch["grid_blocks"], "waves_per_simd": launch["waves_per_simd"]},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        line.update(extras)
+        print(json.dumps(line), flush=True)
+
+    scene.destroy()
+    env.destroy()
+    ctx.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,9 +19,10 @@
  *                         the finite, zero-sign-insensitive uses below
  *   signbit(tLast-tFirst) is evaluated as (tLast < tFirst) so that the sign of
  *   a zero produced by min/max can never steer the traversal (Kernels.h:193).
- * Rays with a non-finite origin/direction/minT/maxT component are undefined
- * behaviour in the reference (the renderer drops them,
+ * Rays with a non-finite origin/direction/minT component or a NaN maxT are
+ * undefined behaviour in the reference (the renderer drops them,
  * PathTracingRenderer.cpp:405-408); here they are defined to miss with rgb=0.
+ * maxT = +inf is valid and follows the kernel's arithmetic literally.
  *
  * Build: gcc -O2 -ffp-contract=off -mfma (see oracle/Makefile).
  */
@@ -174,7 +175,7 @@ static void traverse_one(const orc_gpu_node* nodes, const orc_pair* pairs, const
     for (int k = 0; k < 3; ++k) { ray.o[k] = in->origin[k]; ray.d[k] = in->dir[k]; }
     ray.tNear = in->minT; ray.tFar = in->maxT;
 
-    int finite = isfinite(ray.tNear) && isfinite(ray.tFar);
+    int finite = isfinite(ray.tNear) && !isnan(ray.tFar); /* maxT = +inf is a legitimate "no limit" */
     for (int k = 0; k < 3; ++k) finite = finite && isfinite(ray.o[k]) && isfinite(ray.d[k]);
     if (!finite) {
         out->triangle = 0xFFFFFFFFu; out->t = out->u = out->v = 0.0f;

@@ -49,12 +49,13 @@ struct TraverseArgs {
     const uint32_t* remap;
     const float4* env;        // RGBA32F probe image or nullptr
     uint32_t envW, envH;
-    uint32_t* cursor;         // [0] ray cursor, [1] finished-block counter
+    uint32_t* cursor;         // [0] ray cursor, [1] finished-block counter, [2] watchdog trips
     uint32_t* spill;          // [spillLevels][gridThreads]
     uint32_t spillStride;     // gridThreads
     uint32_t chunk;           // rays per cursor dequeue
     uint32_t refillMin;       // idle lanes that trigger a refill
     uint32_t leafMin;         // leaf lanes that trigger a leaf step
+    uint32_t maxIters;        // watchdog: a wave gives up after this many scheduling iterations
 };
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -186,7 +187,11 @@ __global__ void __launch_bounds__(kBlock) traverseKernel(const TraverseArgs a) {
     uint32_t wBeg = 0, wEnd = 0;        // wave's private chunk of the batch (wave-uniform)
     bool exhausted = false;             // wave-uniform: the global cursor ran past the batch
 
-    for (;;) {
+    for (uint32_t iter = 0;; ++iter) {
+        if (iter >= a.maxIters) {       // bounded spin: never hang the GPU on a corrupt scene
+            if (lane == 0) atomicAdd(a.cursor + 2, 1u);
+            break;
+        }
         const uint64_t innerMask = __ballot(int(node) < 0);
         const uint64_t idleMask = __ballot(node < kLeafBase);
         const uint32_t nInner = __popcll(innerMask);
@@ -433,6 +438,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.chunk = chunk;
     a.refillMin = optOr(ctx->opts.refill_min, 16u);
     a.leafMin = optOr(ctx->opts.leaf_min, 24u);
+    a.maxIters = 1u << 24;
     hipLaunchKernelGGL(traverseKernel<kLdsLevels>, dim3(blocks), dim3(kBlock), 0, stream, a);
     HIP_TRY(hipGetLastError(), "launch traverseKernel");
     lane.info.grid_blocks = blocks;

@@ -1,0 +1,43 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Make sure the oracle and the HIP library exist (hipcc cross-compiles on CPU-only hosts)."""
+    from oracle import oracle
+    import rayaccel_amd
+
+    oracle.build()
+    rayaccel_amd.build_library()
+    yield
+
+
+@pytest.fixture(scope="session")
+def small_scene():
+    from rayaccel_amd import synth
+    return synth.battlefield_synth(grid=40, boxes=32, quads=100)
+
+
+@pytest.fixture(scope="session")
+def small_host(small_scene):
+    import rayaccel_amd
+    return rayaccel_amd.HostScene(small_scene["vertices"], small_scene["indices"])
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    import rayaccel_amd
+    ctx = rayaccel_amd.Context(device=0)     # raises (never falls back) when the extension or GPU is missing
+    yield ctx
+    ctx.destroy()

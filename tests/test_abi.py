@@ -1,0 +1,55 @@
+"""CPU tests of the drop-in boundary: libracc_hip.so loads and exports exactly what include/racc_hip.h
+declares; no compute entry point is callable without a GPU, and nothing falls back to the CPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import rayaccel_amd as ra
+from rayaccel_amd import engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "racc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(racc_(?:hip|host)_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 25
+    lib = C.CDLL(engine.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "header declares %s but libracc_hip.so does not export it" % n
+    assert sorted(engine.ABI) == names, "python binding and header disagree"
+    assert ra.load_library().racc_hip_version().startswith(b"racc-hip")
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(engine.Options) == 16 * 4
+    assert C.sizeof(engine.SceneInfo) == 32 and C.sizeof(engine.LaunchInfo) == 20
+    assert ra.RAY_DTYPE.itemsize == 32 and ra.RESULT_DTYPE.itemsize == 16
+
+
+def test_library_links_no_oracle_and_no_torch():
+    """The product must not route through the oracle or any CPU fallback."""
+    out = os.popen("ldd %s" % engine.LIB_PATH).read()
+    assert "oracle" not in out and "torch" not in out
+    syms = os.popen("nm -D %s" % engine.LIB_PATH).read()
+    assert "orc_" not in syms
+    for root, _, files in os.walk(os.path.join(ROOT, "rayaccel_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(import oracle|from oracle)", src, flags=re.M), f
+                assert not re.search(r"#include\s*[<\"][^>\"]*oracle", src) and "libracc_oracle" not in src, f
+
+
+@pytest.mark.skipif(ra.device_count() > 0, reason="only meaningful on a host without a GPU")
+def test_fails_loudly_without_gpu():
+    with pytest.raises(ra.RaccError) as e:
+        ra.Context(device=0)
+    assert e.value.code == -3 and "no CPU fallback" in str(e.value)

@@ -1,0 +1,61 @@
+"""world_size-2 gloo test of the N>1 path (ray sharding + Result all-gather) on CPU.  The GPU engine
+cannot run here, so each rank uses the ORACLE as its intersector — the thing under test is the sharding
+/ gather plumbing of rayaccel_amd/shard.py, which is device-agnostic."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from rayaccel_amd.shard import shard_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_tiles_the_batch():
+    for count in (0, 1, 7, 64, 1000003):
+        for world in (1, 2, 3, 8):
+            edges = [shard_range(count, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == count
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            sizes = [e - b for b, e in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    from rayaccel_amd import synth
+    from rayaccel_amd.shard import allgather_results, shard_range as sr
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = synth.battlefield_synth(grid=24, boxes=12, quads=40)
+        blobs = orc.build_scene(sc["vertices"], sc["indices"])          # scene replicated on every rank
+        rays = synth.random_rays(4099, seed=9, ymax=30.0)               # odd count: ragged shards
+        b, e = sr(len(rays), rank, world)
+        local = orc.traverse(blobs, rays[b:e])
+        t = torch.from_numpy(local.view(np.uint32).reshape(-1, 4).astype(np.int64)).to(torch.int32)
+        full = allgather_results(t, len(rays), world, dist, torch).numpy().astype(np.uint32)
+        want = orc.traverse(blobs, rays).view(np.uint32).reshape(-1, 4)
+        q.put((rank, bool(np.array_equal(full, want)), e - b))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_allgather():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=180) for _ in procs)
+    [p.join(60) for p in procs]
+    assert [r[1] for r in res] == [True, True]
+    assert sum(r[2] for r in res) == 4099

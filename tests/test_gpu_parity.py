@@ -1,0 +1,235 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the oracle on the same
+seeded inputs.  Bar: primId bit-exact; t/u/v bit-exact as well (same IEEE expression tree on both sides;
+north_star only asks for 1e-4 rel); miss colours within 1e-5 (acosf differs between libm and ocml)."""
+import threading
+
+import numpy as np
+import pytest
+
+import rayaccel_amd as ra
+from oracle import oracle as orc
+from rayaccel_amd import synth
+from helpers import MISS, assert_bit_exact, assert_matches_arbiter, comb_scene, make_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small(gpu_ctx, small_scene, small_host):
+    scene = gpu_ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
+    env = gpu_ctx.create_environment(small_scene["env"])
+    prim, _ = synth.primary_rays(small_scene["camera"], 256, 256)
+    yield dict(scene=scene, env=env, blobs=small_host.blobs(), primary=prim, sc=small_scene)
+    scene.destroy()
+    env.destroy()
+
+
+def _batches(small):
+    prim = small["primary"]
+    hits = orc.traverse(small["blobs"], prim)
+    return {"primary": prim, "diffuse": synth.diffuse_bounce_rays(small["sc"], prim, hits, 50000),
+            "random": synth.random_rays(30011, seed=11, ymax=30.0)}
+
+
+@pytest.mark.parametrize("kind", ["primary", "diffuse", "random"])
+def test_bit_exact_vs_oracle(gpu_ctx, small, kind):
+    rays = _batches(small)[kind]
+    ref = orc.traverse(small["blobs"], rays, env=small["sc"]["env"])
+    got = gpu_ctx.intersect(small["scene"], small["env"], rays)
+    assert_bit_exact(got, ref, kind)
+
+
+def test_golden_vectors_on_gpu(gpu_ctx):
+    import json, os
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    data = np.load(os.path.join(g, "golden_small.npz"))
+    scene = gpu_ctx.upload_scene(data["nodes"].view(orc.GPU_NODE_DTYPE).reshape(-1), data["pairs"].view(orc.PAIR_DTYPE).reshape(-1), data["remap"])
+    env = gpu_ctx.create_environment(data["env"])
+    got = gpu_ctx.intersect(scene, env, data["rays"].view(orc.RAY_DTYPE).reshape(-1))
+    assert_bit_exact(got, data["results"].view(orc.RESULT_DTYPE).reshape(-1), "golden")
+    assert int((got["triangle"] != MISS).sum()) == json.load(open(os.path.join(g, "golden_small.json")))["hits"]
+    scene.destroy(); env.destroy()
+
+
+def test_arbiter_acceptance(gpu_ctx, small):
+    """north_star's criterion judged by the independent double-precision brute force."""
+    rays = np.concatenate([small["primary"][::16], _batches(small)["diffuse"][:3000]])
+    got = gpu_ctx.intersect(small["scene"], small["env"], rays)
+    assert_matches_arbiter(got, small["sc"], rays)
+
+
+def test_create_scene_end_to_end(gpu_ctx, small):
+    """≙ racc::createScene: product host build + upload, vs the oracle's own build of the same mesh."""
+    sc = small["sc"]
+    scene = gpu_ctx.create_scene(sc["vertices"], sc["indices"])
+    ref = orc.traverse(orc.build_scene(sc["vertices"], sc["indices"]), small["primary"], env=sc["env"])
+    assert_bit_exact(gpu_ctx.intersect(scene, small["env"], small["primary"]), ref, "createScene")
+    scene.destroy()
+
+
+@pytest.mark.parametrize("count", [0, 1, 63, 64, 65, 257, 4097])
+def test_ragged_counts(gpu_ctx, small, count):
+    rays = small["primary"][:count]
+    got = gpu_ctx.intersect(small["scene"], small["env"], rays)
+    assert len(got) == count
+    if count:
+        assert_bit_exact(got, orc.traverse(small["blobs"], rays, env=small["sc"]["env"]), "count=%d" % count)
+
+
+def test_no_environment_gives_black_misses(gpu_ctx, small):
+    got = gpu_ctx.intersect(small["scene"], None, small["primary"])
+    ref = orc.traverse(small["blobs"], small["primary"], env=None)
+    assert_bit_exact(got, ref, "no env")
+    miss = ref["triangle"] == MISS
+    assert miss.any() and (got["t"][miss] == 0).all()
+
+
+def test_invalid_and_unbounded_rays(gpu_ctx, small):
+    rays = small["primary"][:512].copy()
+    rays["dir"][5, 1] = np.nan
+    rays["origin"][77, 0] = np.inf
+    rays["minT"][130] = -np.inf
+    rays["maxT"][200] = np.nan
+    rays["maxT"][300:400] = np.inf          # valid: no far limit
+    rays["dir"][401] = (0.0, -0.0, 1.0)     # clamped to +-1e-10
+    got = gpu_ctx.intersect(small["scene"], small["env"], rays)
+    ref = orc.traverse(small["blobs"], rays, env=small["sc"]["env"])
+    assert_bit_exact(got, ref, "invalid rays")
+    for i in (5, 77, 130, 200):
+        assert got["triangle"][i] == MISS and got["t"][i] == 0 and got["u"][i] == 0 and got["v"][i] == 0
+
+
+def test_deep_stack_spills_to_global(gpu_ctx):
+    blobs = comb_scene(40)
+    scene = gpu_ctx.upload_scene(blobs["nodes"], blobs["pairs"], blobs["remap"])
+    assert scene.info["inner_height"] == 40 and scene.info["spill_levels"] == 24
+    o = np.stack([np.linspace(-20, 20, 300), np.linspace(-15, 15, 300), np.full(300, -10.0)], 1)
+    rays = make_rays(o, [[0, 0, 1]] * 300)
+    ref, _, _, depth = orc.traverse(blobs, rays, counters=True)
+    assert depth.max() == 40
+    assert_bit_exact(gpu_ctx.intersect(scene, None, rays), ref, "comb")
+    scene.destroy()
+
+
+def test_malformed_blobs_are_rejected(gpu_ctx, small_host):
+    nodes = small_host.nodes.copy()
+    with pytest.raises(ra.RaccError):                      # cycle: node 1 points back to the root
+        bad = nodes.copy(); bad["first"][1] = 0x80000000
+        gpu_ctx.upload_scene(bad, small_host.pairs, small_host.remap)
+    with pytest.raises(ra.RaccError):                      # child index out of range
+        bad = nodes.copy(); bad["last"][0] = 0x80000000 | len(nodes)
+        gpu_ctx.upload_scene(bad, small_host.pairs, small_host.remap)
+    with pytest.raises(ra.RaccError):                      # leaf range past the pairs
+        bad = nodes.copy(); bad["first"][0] = (5 << 24) | (len(small_host.pairs) - 2)
+        gpu_ctx.upload_scene(bad, small_host.pairs, small_host.remap)
+    with pytest.raises(ra.RaccError):
+        gpu_ctx.upload_scene(nodes[:0], small_host.pairs, small_host.remap)
+
+
+def test_launch_options_do_not_change_results(small_scene, small_host, small):
+    rays = _batches(small)["diffuse"]
+    ref = orc.traverse(small["blobs"], rays, env=small_scene["env"])
+    for opt in (dict(waves_per_simd=1, refill_min=1, leaf_min=1, chunk=1), dict(waves_per_simd=8, refill_min=64, leaf_min=64, chunk=4096),
+                dict(waves_per_simd=3, refill_min=20, leaf_min=7, chunk=100), dict(lanes=1, chunk=64)):
+        with ra.Context(device=0, **opt) as ctx:
+            scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
+            env = ctx.create_environment(small_scene["env"])
+            assert_bit_exact(ctx.intersect(scene, env, rays), ref, str(opt))
+            assert_bit_exact(ctx.intersect(scene, env, rays), ref, str(opt) + " relaunch")   # cursor re-armed by the kernel
+            scene.destroy(); env.destroy()
+
+
+def test_concurrent_lanes_and_device_path(gpu_ctx, small):
+    """≙ gpuSubmissionThreads: distinct lanes driven from distinct host threads (RayAccelerator.cpp:711-717)."""
+    batches = _batches(small)
+    names = list(batches)
+    refs = {k: orc.traverse(small["blobs"], batches[k], env=small["sc"]["env"]) for k in names}
+    out, errs = {}, []
+
+    def work(lane, k):
+        try:
+            for _ in range(3):
+                out[k] = gpu_ctx.intersect(small["scene"], small["env"], batches[k], lane=lane)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i, k)) for i, k in enumerate(names)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs
+    for k in names:
+        assert_bit_exact(out[k], refs[k], "lane " + k)
+    # device-resident entry point (bench path)
+    rays = batches["random"]
+    d_r, d_o = gpu_ctx.alloc(rays.nbytes), gpu_ctx.alloc(len(rays) * 16)
+    d_r.upload(rays)
+    ms = gpu_ctx.intersect_device_timed(small["scene"], small["env"], d_r.ptr, d_o.ptr, len(rays), 4, lane=3)
+    assert len(ms) == 4 and all(m > 0 for m in ms)
+    assert_bit_exact(d_o.download(ra.RESULT_DTYPE, len(rays)), refs["random"], "device path")
+    gpu_ctx.intersect_device(small["scene"], small["env"], d_r.ptr, d_o.ptr, 1000, lane=2); gpu_ctx.wait(2)
+    assert_bit_exact(d_o.download(ra.RESULT_DTYPE, 1000), refs["random"][:1000], "device path async")
+    d_r.free(); d_o.free()
+
+
+def test_order_independence_and_split_batches(gpu_ctx, small):
+    rays = _batches(small)["diffuse"][:20000]
+    whole = gpu_ctx.intersect(small["scene"], small["env"], rays)
+    perm = np.random.default_rng(5).permutation(len(rays))
+    shuffled = gpu_ctx.intersect(small["scene"], small["env"], rays[perm])
+    assert np.array_equal(shuffled.view(np.uint8).reshape(-1, 16), whole.view(np.uint8).reshape(-1, 16)[perm])
+    parts = np.concatenate([gpu_ctx.intersect(small["scene"], small["env"], rays[a:b]) for a, b in ((0, 777), (777, 12000), (12000, 20000))])
+    assert np.array_equal(parts.view(np.uint8), whole.view(np.uint8))
+
+
+# ---------------------------------------------------------------- BASELINE.json full sizes
+@pytest.fixture(scope="module")
+def full(gpu_ctx):
+    sc = synth.battlefield_synth()
+    host = ra.HostScene(sc["vertices"], sc["indices"])
+    scene = gpu_ctx.upload_scene(host.nodes, host.pairs, host.remap)
+    env = gpu_ctx.create_environment(sc["env"])
+    prim, _ = synth.primary_rays(sc["camera"], 1024, 1024)
+    yield dict(sc=sc, host=host, scene=scene, env=env, primary=prim)
+    scene.destroy(); env.destroy()
+
+
+def test_full_size_1M_coherent_and_diffuse(gpu_ctx, full):
+    """BASELINE configs[1] and [2] at full size: bit-exact vs the oracle (it finishes in ~1 s per batch)
+    plus size-independent properties."""
+    blobs, sc = full["host"].blobs(), full["sc"]
+    got = gpu_ctx.intersect(full["scene"], full["env"], full["primary"])
+    assert_bit_exact(got, orc.traverse(blobs, full["primary"], env=sc["env"], threads=8), "1M coherent")
+    bounce = synth.diffuse_bounce_rays(sc, full["primary"], got, 1 << 20)
+    got2 = gpu_ctx.intersect(full["scene"], full["env"], bounce)
+    assert_bit_exact(got2, orc.traverse(blobs, bounce, env=sc["env"], threads=8), "1M diffuse")
+    # idempotence
+    assert np.array_equal(gpu_ctx.intersect(full["scene"], full["env"], bounce).view(np.uint8), got2.view(np.uint8))
+    # closed at maxT: clamping every hit ray's maxT to its own t must keep the same triangle unless the
+    # box-sentinel quirk culls it; never a DIFFERENT triangle, never a nearer t
+    hit = np.nonzero(got2["triangle"] != MISS)[0][:200000]
+    clamp = bounce[hit].copy(); clamp["maxT"] = got2["t"][hit]
+    again = gpu_ctx.intersect(full["scene"], full["env"], clamp)
+    same = again["triangle"] == got2["triangle"][hit]
+    assert (same | (again["triangle"] == MISS)).all() and same.mean() > 0.99
+    assert np.array_equal(again["t"][same].view(np.uint32), got2["t"][hit][same].view(np.uint32))
+    # open at minT: starting each ray AT its hit distance must find something strictly farther (or nothing)
+    beyond = bounce[hit].copy(); beyond["minT"] = got2["t"][hit]
+    far = gpu_ctx.intersect(full["scene"], full["env"], beyond)
+    fh = far["triangle"] != MISS
+    assert (far["t"][fh] > got2["t"][hit][fh]).all()
+    # reversibility: shooting back from each hit point toward the origin must not be blocked before the origin
+    P = bounce["origin"][hit] + bounce["dir"][hit] * got2["t"][hit][:, None]
+    back = make_rays(P, -bounce["dir"][hit], min_t=1e-3, max_t=1.0)
+    back["maxT"] = got2["t"][hit] * np.float32(0.999) - np.float32(2e-3)
+    ok = back["maxT"] > back["minT"]
+    blocked = gpu_ctx.intersect(full["scene"], None, back[ok])["triangle"] != MISS
+    assert blocked.mean() < 1e-3
+
+
+def test_full_size_4M_batch(gpu_ctx, full):
+    """Maximum-size case: a 4M-ray batch (4 x the bench batch) equals four 1M launches."""
+    rays = np.concatenate([full["primary"]] * 4)
+    rays["origin"][1 << 20:] += np.float32(0.25)
+    big = gpu_ctx.intersect(full["scene"], full["env"], rays)
+    q = 1 << 20
+    for k in range(4):
+        part = gpu_ctx.intersect(full["scene"], full["env"], rays[k * q:(k + 1) * q])
+        assert np.array_equal(part.view(np.uint8), big[k * q:(k + 1) * q].view(np.uint8))

@@ -1,0 +1,72 @@
+"""CPU tests of the product's host-side scene build (rayaccel_amd/csrc/scene_build.cpp) against the
+oracle's restatement of Bvh2.cpp / Scene.cpp: index and byte work, so BIT-EXACT."""
+import numpy as np
+import pytest
+
+import rayaccel_amd as ra
+from oracle import oracle as orc
+from rayaccel_amd import synth
+
+
+@pytest.mark.parametrize("kw", [dict(grid=8, boxes=2, quads=5), dict(grid=40, boxes=32, quads=100),
+                                dict(grid=96, boxes=200, quads=900), dict(grid=3, boxes=0, quads=0)])
+def test_builder_and_packer_match_oracle(kw):
+    sc = synth.battlefield_synth(**kw)
+    hs = ra.HostScene(sc["vertices"], sc["indices"])
+    nodes, tris = orc.bvh2_build(sc["vertices"], sc["indices"])
+    assert np.array_equal(hs.bvh_nodes.view(np.uint8), nodes.view(np.uint8))       # tree incl. float bounds
+    assert np.array_equal(hs.bvh_triangles, tris)                                   # leaf triangle order
+    blobs = orc.scene_pack(nodes, tris, sc["vertices"], sc["indices"])
+    assert np.array_equal(hs.nodes.view(np.uint8), blobs["nodes"].view(np.uint8))   # 64 B inner nodes
+    assert np.array_equal(hs.pairs.view(np.uint8), blobs["pairs"].view(np.uint8))   # 48 B pairs incl. padding
+    assert np.array_equal(hs.remap, blobs["remap"]) and hs.pair_count == blobs["pair_count"]
+
+
+def test_blob_invariants(small_scene, small_host):
+    T = len(small_scene["indices"])
+    hs = small_host
+    assert (len(hs.pairs) * 3) % 32 == 0 and len(hs.pairs) > hs.pair_count          # Scene.cpp:334-338 (>=1 pad pair)
+    assert np.array_equal(hs.pairs[hs.pair_count:].view(np.uint8).reshape(-1, 48), np.tile(hs.pairs[:1].view(np.uint8), (len(hs.pairs) - hs.pair_count, 1)))
+    ids = hs.remap & 0x3FFFFFFF
+    second_real = (hs.remap[1::2] >> 30) != 0                                       # second slot used iff edge code != 0
+    used = np.concatenate([ids[0::2], ids[1::2][second_real]])
+    assert np.array_equal(np.sort(used), np.arange(T))                               # every triangle exactly once
+    kids = np.concatenate([hs.nodes["first"], hs.nodes["last"]])
+    leaves = kids[(kids & 0x80000000) == 0]
+    first, cnt = leaves & 0xFFFFFF, leaves >> 24
+    order = np.argsort(first)
+    assert cnt.min() >= 1 and cnt.max() <= 127
+    assert np.array_equal(first[order][1:], (first + cnt)[order][:-1]) and (first + cnt).max() == hs.pair_count   # ranges tile the pairs
+    inner = kids[(kids & 0x80000000) != 0] & 0x7FFFFFFF
+    assert np.array_equal(np.sort(inner), np.arange(1, len(hs.nodes)))               # a tree: every inner node but the root has one parent
+
+
+def test_pairing_rate_on_connected_mesh(small_host, small_scene):
+    assert small_host.pair_count < 0.56 * len(small_scene["indices"])                # ~0.5 pairs/triangle when well connected
+
+
+def test_build_is_deterministic(small_scene):
+    a = ra.HostScene(small_scene["vertices"], small_scene["indices"])
+    b = ra.HostScene(small_scene["vertices"], small_scene["indices"])
+    assert np.array_equal(a.nodes.view(np.uint8), b.nodes.view(np.uint8)) and np.array_equal(a.remap, b.remap)
+
+
+def test_error_behaviour():
+    lib = ra.load_library()
+    import ctypes as C
+    v = np.zeros((8, 4), np.float32)
+    h = C.c_void_p()
+    idx = np.arange(6, dtype=np.uint32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.racc_host_scene_build(vp(v), 8, vp(idx), 5, C.byref(h)) == -1                 # index_count % 3 (Scene.cpp:186)
+    assert b"multiple of 3" in lib.racc_hip_last_error()
+    assert lib.racc_host_scene_build(vp(v), 8, vp(idx), 6, C.byref(h)) == -4 and not h      # 2 triangles: root would be a leaf
+    bad = np.array([0, 1, 99, 0, 1, 2, 1, 2, 3], np.uint32)
+    assert lib.racc_host_scene_build(vp(v), 8, vp(bad), 9, C.byref(h)) == -1                 # vertex index out of range
+    mis = np.zeros(64, np.float32)
+    off = 1 if mis.ctypes.data % 16 == 0 else 0
+    addr = mis.ctypes.data + 4 * off
+    assert addr % 16 != 0
+    assert lib.racc_host_scene_build(C.c_void_p(addr), 8, vp(np.arange(9, dtype=np.uint32) % 8), 9, C.byref(h)) == -1   # Scene.cpp:187
+    with pytest.raises(ra.RaccError):
+        ra.HostScene(v, idx[:3])
