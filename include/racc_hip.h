@@ -123,6 +123,10 @@ int racc_hip_intersect_device_timed(racc_hip_ctx* ctx, const racc_hip_scene* sce
                                     const void* d_rays, void* d_results, uint32_t count,
                                     uint32_t lane, uint32_t iters, float* ms);
 int racc_hip_get_launch_info(racc_hip_ctx* ctx, uint32_t lane, racc_hip_launch_info* info);
+/* Scheduling statistics accumulated by the debug kernel variant (kernel_variant 9) on a lane:
+ * [0] inner-step iterations [1] lanes active in them [2] leaf-step iterations [3] lanes active in them
+ * [4] refill iterations [5] rays loaded [6] cursor dequeues [7] waves.  Waits for the lane. */
+int racc_hip_read_stats(racc_hip_ctx* ctx, uint32_t lane, uint64_t* stats8, int reset);
 
 /* Device memory helpers for hosts that do not bring their own allocator. */
 int racc_hip_malloc(racc_hip_ctx* ctx, uint64_t bytes, void** d_ptr);

@@ -165,6 +165,10 @@ void orc_env_sample(const float* env, uint32_t envW, uint32_t envH, const float 
                + (1.0f - a) * b * t01[c] + a * b * t11[c];
 }
 
+/* Optional per-node visit histogram (analysis aid for device-layout decisions). */
+static uint32_t* g_visit_hist = 0;
+void orc_set_visit_histogram(uint32_t* hist) { g_visit_hist = hist; }
+
 /* ------------------------------------------ Kernels.h:139-242 (`traversal`) */
 static void traverse_one(const orc_gpu_node* nodes, const orc_pair* pairs, const uint32_t* remap,
                          const float* env, uint32_t envW, uint32_t envH,
@@ -201,6 +205,7 @@ static void traverse_one(const orc_gpu_node* nodes, const orc_pair* pairs, const
         if (node & 0x80000000u) {
             const orc_gpu_node* n = nodes + (node & 0x7FFFFFFFu);
             ++nv;
+            if (g_visit_hist) __atomic_fetch_add(&g_visit_hist[node & 0x7FFFFFFFu], 1u, __ATOMIC_RELAXED);
             const float tRay = ray.tFar;
             const float tFirst = aabb_intersect(n->leftMin, n->leftMax, &ray, invDir, OoD);
             const float tLast = aabb_intersect(n->rightMin, n->rightMax, &ray, invDir, OoD);

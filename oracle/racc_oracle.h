@@ -72,6 +72,9 @@ void orc_traverse(const orc_gpu_node* nodes, const orc_pair* pairs, const uint32
                   const orc_ray* rays, orc_result* results, uint32_t start, uint32_t end,
                   uint32_t* nv, uint32_t* np, uint32_t* depth);
 
+/* Analysis aid: when set (non-NULL), every inner-node visit increments hist[node]. */
+void orc_set_visit_histogram(uint32_t* hist);
+
 /* Same as orc_traverse over [0,count) in slices of `slice` rays
  * (cpuTestBatch = 1024, RayAccelerator.cpp:197-212,438) on `threads` pthreads.
  * Used by bench.py's cpu_baseline leg ("port"). */

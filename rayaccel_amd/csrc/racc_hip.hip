@@ -27,6 +27,8 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <queue>
+#include <utility>
 #include <vector>
 
 #include "racc_hip.h"
@@ -35,8 +37,7 @@ extern "C" void racc_hip_set_error_(const char* msg);
 
 namespace {
 
-constexpr int kBlock = 256;        // 4 waves: one per SIMD of a CU
-constexpr int kLdsLevels = 16;     // stack levels resident in LDS (16 KiB per block)
+constexpr int kCacheMax = 4096;    // nodes re-ordered to the front of the device array (upper bound of any variant's LDS cache)
 constexpr uint32_t kInvalidTriangle = 0xFFFFFFFFu;
 constexpr uint32_t kLeafBase = 0x1000000u;   // node refs below this carry no work (done / empty lane)
 
@@ -44,7 +45,9 @@ struct TraverseArgs {
     const float4* rays;
     float4* results;
     uint32_t count;
-    const float4* nodes;      // 4 x float4 per inner node (Scene.cpp:73-78 order)
+    const float4* nodes;      // 4 x float4 per inner node (Scene.cpp:73-78 order); the first
+                              // `cacheCount` are the largest-area top of the tree (see reorderNodes)
+    uint32_t cacheCount;      // nodes [0, cacheCount) are also resident in LDS
     const float4* pairs;      // 3 x float4 per pair (Scene.cpp:83-87 order)
     const uint32_t* remap;
     const float4* env;        // RGBA32F probe image or nullptr
@@ -56,6 +59,8 @@ struct TraverseArgs {
     uint32_t refillMin;       // idle lanes that trigger a refill
     uint32_t leafMin;         // leaf lanes that trigger a leaf step
     uint32_t maxIters;        // watchdog: a wave gives up after this many scheduling iterations
+    unsigned long long* stats;   // STATS builds only: [0] inner iters [1] inner lanes [2] leaf iters [3] leaf lanes
+                                 //                    [4] refill iters [5] rays loaded [6] dequeues [7] waves
 };
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -169,13 +174,29 @@ __device__ __forceinline__ uint32_t laneRank(uint64_t mask) {   // # set bits be
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
 
-template <int LDS_LEVELS>
-__global__ void __launch_bounds__(kBlock) traverseKernel(const TraverseArgs a) {
-    __shared__ uint32_t ldsStack[LDS_LEVELS * kBlock];
+// BLOCK threads per workgroup; LDS_LEVELS stack levels per ray in LDS; CACHE_NODES top-of-tree nodes in LDS.
+template <int BLOCK, int LDS_LEVELS, int CACHE_NODES, bool STATS = false>
+__global__ void __launch_bounds__(BLOCK) traverseKernel(const TraverseArgs a) {
+    // One LDS object: [node cache: CACHE_NODES x 64 B, XOR-swizzled][stack: LDS_LEVELS x BLOCK words].
+    __shared__ __attribute__((aligned(16))) uint32_t lds[CACHE_NODES * 16 + LDS_LEVELS * BLOCK];
+    constexpr int kBlock = BLOCK;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    uint32_t* const myLds = ldsStack + tid;                                  // level stride kBlock
+    uint32_t* const myLds = lds + CACHE_NODES * 16 + tid;                    // level stride BLOCK: bank = tid % 32 at every level
     uint32_t* const mySpill = a.spill + (blockIdx.x * kBlock + tid);         // level stride a.spillStride
+    const float4* const ldsNodes = reinterpret_cast<const float4*>(lds);
+
+    if (CACHE_NODES > 0) {
+        // Stage the hottest nodes once per workgroup.  float4 #q of node n lives at slot q ^ ((n >> 2) & 3) of the
+        // node's 64 B row, so a 16-lane ds_read_b128 group reading q of random nodes spreads over all 16 slot
+        // positions of the 256 B bank row instead of 4.
+        float4* w = reinterpret_cast<float4*>(lds);
+        for (uint32_t i = tid; i < a.cacheCount * 4u; i += BLOCK) {
+            const uint32_t n = i >> 2, q = i & 3u;
+            w[n * 4u + (q ^ ((n >> 2) & 3u))] = a.nodes[i];
+        }
+        __syncthreads();
+    }
 
     LaneRay r;
     r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = 0.0f;
@@ -186,6 +207,7 @@ __global__ void __launch_bounds__(kBlock) traverseKernel(const TraverseArgs a) {
     uint32_t sp = 0;
     uint32_t wBeg = 0, wEnd = 0;        // wave's private chunk of the batch (wave-uniform)
     bool exhausted = false;             // wave-uniform: the global cursor ran past the batch
+    uint32_t stInner = 0, stInnerLanes = 0, stLeaf = 0, stLeafLanes = 0, stRefill = 0, stLoaded = 0, stDeq = 0;
 
     for (uint32_t iter = 0;; ++iter) {
         if (iter >= a.maxIters) {       // bounded spin: never hang the GPU on a corrupt scene
@@ -220,7 +242,9 @@ __global__ void __launch_bounds__(kBlock) traverseKernel(const TraverseArgs a) {
             // ---------------- refill idle lanes from the wave's chunk ----------------
             const uint64_t emptyMask = __ballot(rayIdx < 0);
             const uint32_t need = __popcll(emptyMask);
+            if (STATS) ++stRefill;
             if (wBeg == wEnd && !exhausted) {
+                if (STATS) ++stDeq;
                 uint32_t b = 0;
                 if (lane == 0) b = atomicAdd(a.cursor, a.chunk);
                 b = __builtin_amdgcn_readfirstlane(b);
@@ -254,12 +278,14 @@ __global__ void __launch_bounds__(kBlock) traverseKernel(const TraverseArgs a) {
                 }
             }
             wBeg += take;
+            if (STATS) stLoaded += take;
             if (exhausted && wBeg == wEnd && __ballot(rayIdx >= 0) == 0ull) break;
             continue;
         }
 
         if (nLeaf >= a.leafMin || nInner == 0u) {
             // ---------------- leaf step: one triangle pair per lane (Kernels.h:200-205) ----------------
+            if (STATS) { ++stLeaf; stLeafLanes += nLeaf; }
             if (int(node) >= int(kLeafBase)) {
                 const uint32_t cur = node & 0xFFFFFFu;
                 const uint32_t cnt = node >> 24;
@@ -270,15 +296,30 @@ __global__ void __launch_bounds__(kBlock) traverseKernel(const TraverseArgs a) {
                     node = 0u;
                 } else {
                     --sp;
-                    node = (sp < uint32_t(LDS_LEVELS)) ? myLds[sp * kBlock] : mySpill[size_t(sp - LDS_LEVELS) * a.spillStride];
+                    node = myLds[min(sp, uint32_t(LDS_LEVELS - 1)) * kBlock];
+                    if (sp >= uint32_t(LDS_LEVELS)) node = mySpill[size_t(sp - LDS_LEVELS) * a.spillStride];
                 }
             }
         } else {
             // ---------------- inner step: two slab tests, descend nearer, push farther (Kernels.h:170-199) ----------------
+            if (STATS) { ++stInner; stInnerLanes += nInner; }
             if (int(node) < 0) {
-                const float4* np = a.nodes + size_t(node & 0x7FFFFFFFu) * 4;
-                const uint2 kids = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(np) + 2);
-                const float4 d1 = np[1], d2 = np[2], d3 = np[3];
+                const uint32_t ni = node & 0x7FFFFFFFu;
+                uint2 kids;
+                float4 d1, d2, d3;
+                if (CACHE_NODES > 0 && ni < a.cacheCount) {           // top of the tree: LDS, off the vector-memory path
+                    const uint32_t sw = (ni >> 2) & 3u;
+                    const float4* lp = ldsNodes + ni * 4u;
+                    const float4 d0 = lp[sw];
+                    kids = make_uint2(__float_as_uint(d0.z), __float_as_uint(d0.w));
+                    d1 = lp[1u ^ sw]; d2 = lp[2u ^ sw]; d3 = lp[3u ^ sw];
+                    asm volatile("" ::: "memory");   // keep these ds_read_b128: without it the two arms are merged into flat loads
+                } else {
+                    const float4* np = a.nodes + size_t(ni) * 4;
+                    kids = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(np) + 2);
+                    d1 = np[1]; d2 = np[2]; d3 = np[3];
+                    asm volatile("" ::: "memory");
+                }
                 const float tRay = r.tFar;
                 const float tFirst = aabbIntersect(d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tNear, tRay);
                 const float tLast = aabbIntersect(d2.z, d2.w, d3.x, d3.y, d3.z, d3.w, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tNear, tRay);
@@ -295,12 +336,19 @@ __global__ void __launch_bounds__(kBlock) traverseKernel(const TraverseArgs a) {
                     node = 0u;
                 } else {
                     --sp;
-                    node = (sp < uint32_t(LDS_LEVELS)) ? myLds[sp * kBlock] : mySpill[size_t(sp - LDS_LEVELS) * a.spillStride];
+                    node = myLds[min(sp, uint32_t(LDS_LEVELS - 1)) * kBlock];
+                    if (sp >= uint32_t(LDS_LEVELS)) node = mySpill[size_t(sp - LDS_LEVELS) * a.spillStride];
                 }
             }
         }
     }
 
+    if (STATS && lane == 0) {
+        atomicAdd(a.stats + 0, (unsigned long long)stInner); atomicAdd(a.stats + 1, (unsigned long long)stInnerLanes);
+        atomicAdd(a.stats + 2, (unsigned long long)stLeaf);  atomicAdd(a.stats + 3, (unsigned long long)stLeafLanes);
+        atomicAdd(a.stats + 4, (unsigned long long)stRefill); atomicAdd(a.stats + 5, (unsigned long long)stLoaded);
+        atomicAdd(a.stats + 6, (unsigned long long)stDeq);   atomicAdd(a.stats + 7, 1ull);
+    }
     // The last block to leave re-arms the cursor for the next launch on this lane (no host memset needed).
     __syncthreads();
     if (tid == 0) {
@@ -398,8 +446,44 @@ int validateScene(const GpuNodeHost* nodes, uint32_t nodeCount, uint32_t pairCou
     info.inner_height = height;
     info.max_leaf_pairs = maxLeaf;
     // A push happens at most once per inner node on the current root path.
-    info.spill_levels = height > uint32_t(kLdsLevels) ? height - uint32_t(kLdsLevels) : 0u;
+    info.spill_levels = 0;   // filled per kernel variant at launch: max(0, height - LDS_LEVELS)
     return RACC_HIP_OK;
+}
+
+// Device node order: the kCacheMax nodes with the largest own bounding-box area first (a node's box is always
+// larger than its children's, so this is a connected top of the tree and every prefix [0,K) of it is the best K
+// by that measure — ~50 % of all node visits for K = 1024 on battlefield-synth, vs 43 % for plain BFS levels),
+// the rest in the reference's order.  Child references are rewritten; results cannot depend on node numbering.
+void reorderNodes(const GpuNodeHost* in, uint32_t n, std::vector<GpuNodeHost>& out) {
+    std::vector<uint32_t> newToOld;
+    newToOld.reserve(n);
+    std::vector<uint8_t> placed(n, 0);
+    auto area = [](const float* b) {   // b = min[3], max[3]
+        const double x = double(b[3]) - b[0], y = double(b[4]) - b[1], z = double(b[5]) - b[2];
+        return x * y + x * z + y * z;
+    };
+    using Item = std::pair<double, uint32_t>;   // (area, -index) max-heap: larger area first, lower index on ties
+    std::priority_queue<Item> heap;
+    heap.emplace(1e300, ~0u);
+    const uint32_t top = n < uint32_t(kCacheMax) ? n : uint32_t(kCacheMax);
+    while (!heap.empty() && newToOld.size() < top) {
+        const uint32_t node = ~heap.top().second;
+        heap.pop();
+        newToOld.push_back(node);
+        placed[node] = 1;
+        if (in[node].first & 0x80000000u) heap.emplace(area(in[node].box + 0), ~(in[node].first & 0x7FFFFFFFu));
+        if (in[node].last & 0x80000000u) heap.emplace(area(in[node].box + 6), ~(in[node].last & 0x7FFFFFFFu));
+    }
+    for (uint32_t i = 0; i < n; ++i) if (!placed[i]) newToOld.push_back(i);
+    std::vector<uint32_t> oldToNew(n);
+    for (uint32_t i = 0; i < n; ++i) oldToNew[newToOld[i]] = i;
+    out.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        GpuNodeHost g = in[newToOld[i]];
+        if (g.first & 0x80000000u) g.first = 0x80000000u | oldToNew[g.first & 0x7FFFFFFFu];
+        if (g.last & 0x80000000u) g.last = 0x80000000u | oldToNew[g.last & 0x7FFFFFFFu];
+        out[i] = g;
+    }
 }
 
 int ensureSpill(racc_hip_ctx* ctx, Lane& lane, uint32_t gridThreads, uint32_t levels) {
@@ -414,37 +498,70 @@ int ensureSpill(racc_hip_ctx* ctx, Lane& lane, uint32_t gridThreads, uint32_t le
 
 uint32_t optOr(uint32_t v, uint32_t dflt) { return v ? v : dflt; }
 
+struct Variant {
+    int block, ldsLevels, cacheNodes;
+    void (*kernel)(const TraverseArgs);
+};
+// kernel_variant n selects kVariants[n-1]; 0 selects kDefaultVariant.  LDS per workgroup = cacheNodes*64 + ldsLevels*block*4.
+const Variant kVariants[] = {
+    {256, 16, 0, traverseKernel<256, 16, 0>},          // 1: no node cache, 16 KiB/WG, up to 8 WG/CU
+    {1024, 12, 1792, traverseKernel<1024, 12, 1792>},  // 2: 160 KiB: 112 KiB cache + 48 KiB stacks, 1 WG/CU (4 waves/SIMD)
+    {1024, 16, 1536, traverseKernel<1024, 16, 1536>},  // 3: 160 KiB: 96 + 64
+    {512, 16, 2048, traverseKernel<512, 16, 2048>},    // 4: 160 KiB: 128 + 32, 1 WG/CU (2 waves/SIMD)
+    {512, 8, 960, traverseKernel<512, 8, 960>},        // 5: 76 KiB: 60 + 16, 2 WG/CU
+    {256, 8, 448, traverseKernel<256, 8, 448>},        // 6: 36 KiB: 28 + 8, 4 WG/CU
+    {1024, 12, 1024, traverseKernel<1024, 12, 1024>},  // 7: 112 KiB: 64 + 48
+    {512, 12, 1024, traverseKernel<512, 12, 1024>},    // 8: 88 KiB: 64 + 24, 1 WG/CU
+    {256, 16, 0, traverseKernel<256, 16, 0, true>},    // 9: variant 1 + scheduling statistics (debug)
+};
+constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
+constexpr int kDefaultVariant = 1;
+constexpr uint32_t kLdsPerCU = 160u * 1024u;
+
+const Variant& pickVariant(const racc_hip_ctx* ctx) {
+    const uint32_t v = ctx->opts.kernel_variant;
+    return kVariants[(v >= 1 && v <= uint32_t(kNumVariants)) ? v - 1 : kDefaultVariant - 1];
+}
+
 int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc_hip_scene* scene, const racc_hip_env* env,
                    const void* dRays, void* dResults, uint32_t count) {
     if (!count) return RACC_HIP_OK;
-    const uint32_t wavesPerSimd = optOr(ctx->opts.waves_per_simd, 8u);
-    const uint32_t chunk = optOr(ctx->opts.chunk, 64u);
-    uint32_t blocks = uint32_t(ctx->numCUs) * wavesPerSimd;                      // 4 waves per block = 1 wave per SIMD
-    const uint32_t blocksNeeded = (count + kBlock - 1) / kBlock;
+    const Variant& v = pickVariant(ctx);
+    const uint32_t ldsBytes = uint32_t(v.cacheNodes) * 64u + uint32_t(v.ldsLevels) * uint32_t(v.block) * 4u;
+    const uint32_t wavesPerSimd = optOr(ctx->opts.waves_per_simd, 5u);   // measured best on 1M-ray batches (profiles/)
+    const uint32_t wavesPerBlock = uint32_t(v.block) / 64u;
+    uint32_t blocksPerCU = (wavesPerSimd * 4u) / wavesPerBlock;
+    if (blocksPerCU < 1u) blocksPerCU = 1u;
+    if (blocksPerCU > kLdsPerCU / ldsBytes) blocksPerCU = kLdsPerCU / ldsBytes;
+    uint32_t blocks = uint32_t(ctx->numCUs) * blocksPerCU;
+    const uint32_t blocksNeeded = (count + uint32_t(v.block) - 1) / uint32_t(v.block);
     if (blocks > blocksNeeded) blocks = blocksNeeded;
-    const uint32_t gridThreads = blocks * kBlock;
-    if (int rc = ensureSpill(ctx, lane, uint32_t(ctx->numCUs) * 8u * kBlock, scene->info.spill_levels)) return rc;
+    const uint32_t gridThreads = blocks * uint32_t(v.block);
+    const uint32_t spillLevels = scene->info.inner_height > uint32_t(v.ldsLevels) ? scene->info.inner_height - uint32_t(v.ldsLevels) : 0u;
+    if (int rc = ensureSpill(ctx, lane, uint32_t(ctx->numCUs) * 2048u, spillLevels)) return rc;
 
     TraverseArgs a;
     a.rays = static_cast<const float4*>(dRays);
     a.results = static_cast<float4*>(dResults);
     a.count = count;
     a.nodes = scene->nodes; a.pairs = scene->pairs; a.remap = scene->remap;
+    a.cacheCount = scene->info.node_count < uint32_t(v.cacheNodes) ? scene->info.node_count : uint32_t(v.cacheNodes);
     a.env = env ? env->pixels : nullptr;
     a.envW = env ? env->width : 0; a.envH = env ? env->height : 0;
     a.cursor = lane.cursor;
     a.spill = lane.spill;
     a.spillStride = gridThreads;
-    a.chunk = chunk;
-    a.refillMin = optOr(ctx->opts.refill_min, 16u);
-    a.leafMin = optOr(ctx->opts.leaf_min, 24u);
+    a.chunk = optOr(ctx->opts.chunk, 64u);
+    a.refillMin = optOr(ctx->opts.refill_min, 32u);
+    a.leafMin = optOr(ctx->opts.leaf_min, 8u);
     a.maxIters = 1u << 24;
-    hipLaunchKernelGGL(traverseKernel<kLdsLevels>, dim3(blocks), dim3(kBlock), 0, stream, a);
+    a.stats = reinterpret_cast<unsigned long long*>(lane.cursor + 8);
+    hipLaunchKernelGGL(v.kernel, dim3(blocks), dim3(v.block), 0, stream, a);
     HIP_TRY(hipGetLastError(), "launch traverseKernel");
     lane.info.grid_blocks = blocks;
-    lane.info.block_threads = kBlock;
-    lane.info.lds_bytes_per_block = kLdsLevels * kBlock * 4;
-    lane.info.waves_per_simd = wavesPerSimd;
+    lane.info.block_threads = uint32_t(v.block);
+    lane.info.lds_bytes_per_block = ldsBytes;
+    lane.info.waves_per_simd = blocksPerCU * wavesPerBlock / 4u;
     return RACC_HIP_OK;
 }
 
@@ -514,8 +631,8 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
     for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
         Lane& l = ctx->lanes[i];
         hipError_t e1 = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
-        hipError_t e2 = e1 == hipSuccess ? hipMalloc(reinterpret_cast<void**>(&l.cursor), 64) : e1;
-        hipError_t e3 = e2 == hipSuccess ? hipMemset(l.cursor, 0, 64) : e2;
+        hipError_t e2 = e1 == hipSuccess ? hipMalloc(reinterpret_cast<void**>(&l.cursor), 256) : e1;
+        hipError_t e3 = e2 == hipSuccess ? hipMemset(l.cursor, 0, 256) : e2;
         if (e3 != hipSuccess) { racc_hip_destroy(ctx); return fail(RACC_HIP_ERR_DEVICE, "lane setup", e3); }
     }
     *out = ctx;
@@ -553,12 +670,18 @@ int racc_hip_scene_upload(racc_hip_ctx* ctx, const void* nodes64, uint32_t node_
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->nodes), nb);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->pairs), pb);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->remap), rb ? rb : 4);
-    if (e == hipSuccess) e = hipMemcpy(s->nodes, nodes64, nb, hipMemcpyHostToDevice);
+    std::vector<GpuNodeHost> ordered;
+    reorderNodes(static_cast<const GpuNodeHost*>(nodes64), node_count, ordered);
+    if (e == hipSuccess) e = hipMemcpy(s->nodes, ordered.data(), nb, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(s->pairs, pairs48, pb, hipMemcpyHostToDevice);
     if (e == hipSuccess && rb) e = hipMemcpy(s->remap, remap, rb, hipMemcpyHostToDevice);
     if (e != hipSuccess) { racc_hip_scene_free(ctx, s); return fail(RACC_HIP_ERR_DEVICE, "scene upload", e); }
     info.node_count = node_count; info.pair_count = pair_count; info.remap_count = remap_count;
     info.device_bytes = nb + pb + rb;
+    {
+        const Variant& v = pickVariant(ctx);
+        info.spill_levels = info.inner_height > uint32_t(v.ldsLevels) ? info.inner_height - uint32_t(v.ldsLevels) : 0u;
+    }
     s->info = info;
     *out = s;
     return RACC_HIP_OK;
@@ -690,6 +813,17 @@ int racc_hip_get_launch_info(racc_hip_ctx* ctx, uint32_t lane, racc_hip_launch_i
     if (int rc = checkLane(ctx, lane)) return rc;
     if (!info) return fail(RACC_HIP_ERR_INVALID, "info is NULL");
     *info = ctx->lanes[lane].info;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_read_stats(racc_hip_ctx* ctx, uint32_t lane, uint64_t* stats8, int reset) {
+    if (int rc = checkLane(ctx, lane)) return rc;
+    if (!stats8) return fail(RACC_HIP_ERR_INVALID, "stats8 is NULL");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    Lane& l = ctx->lanes[lane];
+    HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
+    HIP_TRY(hipMemcpy(stats8, l.cursor + 8, 64, hipMemcpyDeviceToHost), "hipMemcpy stats");
+    if (reset) HIP_TRY(hipMemset(l.cursor + 8, 0, 64), "hipMemset stats");
     return RACC_HIP_OK;
 }
 

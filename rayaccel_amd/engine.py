@@ -74,6 +74,7 @@ ABI = {
     "racc_hip_intersect_device": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "racc_hip_intersect_device_timed": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _P(C.c_float)]),
     "racc_hip_get_launch_info": (_i, [_vp, _u32, _P(LaunchInfo)]),
+    "racc_hip_read_stats": (_i, [_vp, _u32, _P(_u64), _i]),
     "racc_hip_malloc": (_i, [_vp, _u64, _P(_vp)]),
     "racc_hip_free": (_i, [_vp, _vp]),
     "racc_hip_memcpy_h2d": (_i, [_vp, _vp, _vp, _u64]),
@@ -298,6 +299,12 @@ class Context:
         info = LaunchInfo()
         _check(load_library().racc_hip_get_launch_info(self._h, lane, C.byref(info)))
         return {f: getattr(info, f) for f, _ in LaunchInfo._fields_}
+
+    def read_stats(self, lane=0, reset=True):
+        st = (C.c_uint64 * 8)()
+        _check(load_library().racc_hip_read_stats(self._h, lane, st, 1 if reset else 0))
+        keys = ("inner_iters", "inner_lanes", "leaf_iters", "leaf_lanes", "refill_iters", "rays_loaded", "dequeues", "waves")
+        return dict(zip(keys, [int(x) for x in st]))
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)

@@ -130,7 +130,8 @@ def test_launch_options_do_not_change_results(small_scene, small_host, small):
     rays = _batches(small)["diffuse"]
     ref = orc.traverse(small["blobs"], rays, env=small_scene["env"])
     for opt in (dict(waves_per_simd=1, refill_min=1, leaf_min=1, chunk=1), dict(waves_per_simd=8, refill_min=64, leaf_min=64, chunk=4096),
-                dict(waves_per_simd=3, refill_min=20, leaf_min=7, chunk=100), dict(lanes=1, chunk=64)):
+                dict(waves_per_simd=3, refill_min=20, leaf_min=7, chunk=100), dict(lanes=1, chunk=64),
+                *[dict(kernel_variant=v) for v in range(1, 9)]):
         with ra.Context(device=0, **opt) as ctx:
             scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
             env = ctx.create_environment(small_scene["env"])
@@ -202,13 +203,15 @@ def test_full_size_1M_coherent_and_diffuse(gpu_ctx, full):
     assert_bit_exact(got2, orc.traverse(blobs, bounce, env=sc["env"], threads=8), "1M diffuse")
     # idempotence
     assert np.array_equal(gpu_ctx.intersect(full["scene"], full["env"], bounce).view(np.uint8), got2.view(np.uint8))
-    # closed at maxT: clamping every hit ray's maxT to its own t must keep the same triangle unless the
-    # box-sentinel quirk culls it; never a DIFFERENT triangle, never a nearer t
+    # shrinking maxT to just past the reported t must keep the same triangle and the same bits: never a
+    # DIFFERENT triangle, never a nearer t.  ("Just past": t = T*rcp(absDet) is rounded, and the slab test's
+    # mad(min, invDir, -o*invDir) form (Kernels.h:122-123) cancels badly for flat axis-aligned leaf boxes, so
+    # a maxT within a few 1e-6 of t can cull the leaf — the reference's own behaviour, restated exactly.)
     hit = np.nonzero(got2["triangle"] != MISS)[0][:200000]
-    clamp = bounce[hit].copy(); clamp["maxT"] = got2["t"][hit]
+    clamp = bounce[hit].copy(); clamp["maxT"] = got2["t"][hit] * np.float32(1.001) + np.float32(1e-3)
     again = gpu_ctx.intersect(full["scene"], full["env"], clamp)
     same = again["triangle"] == got2["triangle"][hit]
-    assert (same | (again["triangle"] == MISS)).all() and same.mean() > 0.99
+    assert (same | (again["triangle"] == MISS)).all() and same.mean() > 0.999
     assert np.array_equal(again["t"][same].view(np.uint32), got2["t"][hit][same].view(np.uint32))
     # open at minT: starting each ray AT its hit distance must find something strictly farther (or nothing)
     beyond = bounce[hit].copy(); beyond["minT"] = got2["t"][hit]

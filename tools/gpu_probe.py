@@ -27,17 +27,19 @@ def main():
     B1, B2 = orc.algorithmic_bytes(ref, nv, npp), orc.algorithmic_bytes(ref2, nv2, np2)
     print("alg bytes/ray primary %.0f diffuse %.0f; nv %.1f/%.1f np %.2f/%.2f depth %d/%d" % (B1 / len(rays), B2 / len(bounce), nv.mean(), nv2.mean(), npp.mean(), np2.mean(), dp.max(), dp2.max()), flush=True)
     combos = [dict()]
-    for w in (8, 6, 4):
-        for rf in (8, 16, 32):
-            for lf in (8, 24, 40):
-                combos.append(dict(waves_per_simd=w, refill_min=rf, leaf_min=lf))
-    combos += [dict(chunk=c) for c in (128, 256)]
+    for v in range(1, 10):
+        combos.append(dict(kernel_variant=v))
+    for v in (1, 2, 6):
+        for w in (4, 5, 6):
+            combos.append(dict(kernel_variant=v, waves_per_simd=w))
+    for lf, rf in ((4, 32), (8, 24), (8, 40), (12, 32), (16, 32), (8, 16), (8, 8)):
+        combos.append(dict(kernel_variant=9, leaf_min=lf, refill_min=rf, waves_per_simd=5))
     first = True
     for opt in combos:
         with ra.Context(device=0, **opt) as ctx:
             scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
             env = ctx.create_environment(sc["env"])
-            if first:
+            if first or ("kernel_variant" in opt and len(opt) == 1):
                 print("scene info", scene.info, flush=True)
                 got = ctx.intersect(scene, env, rays); parity("primary", got, ref)
                 got2 = ctx.intersect(scene, env, bounce); parity("diffuse", got2, ref2)
@@ -50,7 +52,15 @@ def main():
                 m = float(np.median(ms))
                 out[name] = dict(ms=round(m, 4), mrays=round(len(batch) / m / 1e3, 1), gbs=round(B / m / 1e6, 1))
                 d_r.free(); d_o.free()
-            print(json.dumps(dict(opt=opt, **out)), flush=True)
+            if opt.get("kernel_variant") == 9:
+                ctx.read_stats()
+                d_r = ctx.alloc(bounce.nbytes); d_o = ctx.alloc(len(bounce) * 16); d_r.upload(bounce)
+                ctx.intersect_device_timed(scene, env, d_r.ptr, d_o.ptr, len(bounce), 1)
+                st = ctx.read_stats(); d_r.free(); d_o.free()
+                st["inner_util"] = round(st["inner_lanes"] / max(1, st["inner_iters"]) / 64, 3)
+                st["leaf_util"] = round(st["leaf_lanes"] / max(1, st["leaf_iters"]) / 64, 3)
+                out["stats_diffuse"] = st
+            print(json.dumps(dict(opt=opt, launch=ctx.launch_info(), **out)), flush=True)
             scene.destroy(); env.destroy()
 
 if __name__ == "__main__":
