@@ -100,6 +100,10 @@ int racc_hip_env_free(racc_hip_ctx* ctx, racc_hip_env* env);         /* ≙ Envi
  * stream's host arrays so the copies below run at PCIe rate.  Optional. */
 int racc_hip_register_stream(racc_hip_ctx* ctx, void* rays, void* results, uint32_t capacity);
 int racc_hip_unregister_stream(racc_hip_ctx* ctx, void* rays, void* results);
+/* Same for one block that holds many streams (the reference allocates all of them in one block,
+ * RayAccelerator.cpp:547-568). */
+int racc_hip_register_host(racc_hip_ctx* ctx, void* ptr, uint64_t bytes);
+int racc_hip_unregister_host(racc_hip_ctx* ctx, void* ptr);
 
 /* ≙ clSetKernelArg x7 + clEnqueueNDRangeKernel + clFinish on one submission thread's queue,
  * RayAccelerator.cpp:378-404.  Host Ray[count] in, host Result[count] out, in place and in order
@@ -111,6 +115,15 @@ int racc_hip_intersect(racc_hip_ctx* ctx, const racc_hip_scene* scene, const rac
 int racc_hip_intersect_async(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
                              const void* rays, void* results, uint32_t count, uint32_t lane);
 int racc_hip_wait(racc_hip_ctx* ctx, uint32_t lane);
+
+/* MI355X-sized dispatch: a whole set of ray streams in ONE launch.  The reference launches once per
+ * <=27k-ray stream (RayAccelerator.cpp:369-404); 27k rays occupy 5 % of the 524,288 lanes a MI355X keeps
+ * resident and every launch pays the latency of its longest ray, so the scheduler (racc::render) hands over
+ * everything that is ready.  rays[i]/results[i] are host arrays of counts[i] records; results land in place
+ * and in order per stream.  Blocking. */
+int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
+                               uint32_t n_streams, const void* const* rays, void* const* results,
+                               const uint32_t* counts, uint32_t lane);
 
 /* Device-resident variant: d_rays/d_results are device pointers (e.g. torch tensors' data_ptr()).
  * `stream` is a hipStream_t passed as void* (NULL => the lane's own stream).  Asynchronous. */

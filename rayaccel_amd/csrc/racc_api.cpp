@@ -1,0 +1,381 @@
+// racc_api.cpp — the racc:: C++ interface (include/RayAccelerator.h) over the C-ABI (include/racc_hip.h).
+//
+// Counterpart of the reference's RayAccelerator.cpp: context creation (:448-727), the ray-stream state machine
+// driven by CPU worker threads (spawn :48-90, shade :92-156, worker loop :248-333) and GPU submission threads
+// (:335-414), and render() (:738-759).  The callback contract is the reference's: spawn/shade run concurrently on
+// worker threads with thread in [0, cpuThreads), outside the scheduler lock; results land in place, in order.
+//
+// Re-designed for a discrete MI355X instead of a shared-memory iGPU:
+//   * a GPU thread takes EVERY stream that is ready (not one) and hands the set to racc_hip_intersect_streams,
+//     i.e. one persistent-kernel launch per scheduling round: a 27k-ray launch fills 5 % of the chip and still
+//     pays the latency of its longest ray;
+//   * partially filled streams are flushed to the GPU only when nothing on the CPU side can still add rays
+//     (the reference flushes eagerly, RayAccelerator.cpp:360-363, which suits an 8,960-work-item iGPU);
+//   * ray/result arrays live in one page-locked block (≙ CL_MEM_USE_HOST_PTR, :643-644) so PCIe copies are DMA;
+//   * stream ids and sizes are 32-bit (the reference's uint16 ids / sizes cap a stream at 131,070 rays);
+//   * no CPU tracing mode (the reference's is binary-only Embree): allowCpuTracing is ignored.
+
+#include "RayAccelerator.h"
+#include "racc_hip.h"
+
+#include <xmmintrin.h>
+#include <pmmintrin.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace racc {
+
+struct Scene {
+    Context* context;
+    racc_hip_scene* device;
+};
+
+struct Environment {
+    Context* context;
+    racc_hip_env* device;
+};
+
+struct Context {
+    Configuration configuration;
+    racc_hip_ctx* hip = nullptr;
+
+    std::vector<RayStream> streams;
+    char* block = nullptr;           // all rays/results, 4096-aligned per array (reference :523-531,616-631)
+    size_t blockBytes = 0;
+    bool blockPinned = false;
+    uint32_t rayStreamSize = 0;
+
+    std::vector<uint32_t> empty, waitingToBeFilled, readyForTest, readyForShade;
+
+    std::mutex mutex;
+    std::condition_variable wake;
+    bool shouldExit = false;
+    bool moreRaysExist = false;
+    uint32_t raysInFlight = 0;
+    uint32_t cpuBusy = 0;            // workers currently inside a callback
+    uint32_t gpuBusy = 0;            // submission threads currently inside a launch
+    uint64_t rayCount = 0;
+
+    Scene* currentScene = nullptr;
+    Environment* currentEnvironment = nullptr;
+    RenderCallbacks currentCallbacks{};
+
+    std::vector<std::thread> threads;
+};
+
+namespace {
+
+void complain(const char* what) { std::fprintf(stderr, "RayAccelerator: %s\n", what); }
+
+void complainHip(const char* what) { std::fprintf(stderr, "RayAccelerator: %s (%s)\n", what, racc_hip_last_error()); }
+
+void setFlushToZero() {   // reference Threading.h:78-79, RayAccelerator.cpp:419-420
+    _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON);
+    _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON);
+}
+
+uint32_t takeOutputStream(Context* c) {   // reference :60,108: a partly filled stream first, else an empty one
+    uint32_t id;
+    if (!c->waitingToBeFilled.empty()) { id = c->waitingToBeFilled.back(); c->waitingToBeFilled.pop_back(); }
+    else { id = c->empty.back(); c->empty.pop_back(); }
+    return id;
+}
+
+void putBack(Context* c, uint32_t id) {   // reference :77-82,130-135
+    const uint32_t n = c->streams[id].count;
+    if (n >= c->configuration.rayStreamBatchSize) c->readyForTest.push_back(id);
+    else if (n == 0) c->empty.push_back(id);
+    else c->waitingToBeFilled.push_back(id);
+}
+
+bool spawnBlocked(const Context* c) {
+    return !c->moreRaysExist || c->raysInFlight + c->configuration.maxRaysPerSpawn > c->configuration.maxRaysInFlight;
+}
+
+// reference spawnRays, :48-90.  Called and returns with the lock held.
+bool spawnRays(Context* c, std::unique_lock<std::mutex>& lock, unsigned thread) {
+    if (spawnBlocked(c) || (c->waitingToBeFilled.empty() && c->empty.empty())) return false;
+    const RenderCallbacks cb = c->currentCallbacks;
+    const uint32_t maxRaysPerSpawn = c->configuration.maxRaysPerSpawn;
+    const uint32_t id = takeOutputStream(c);
+    RayStream* stream = &c->streams[id];
+    c->raysInFlight += maxRaysPerSpawn;
+    ++c->cpuBusy;
+    lock.unlock();
+    const uint32_t before = stream->count;
+    const bool more = cb.spawn(cb.data, thread, stream);
+    const uint32_t added = stream->count - before;
+    lock.lock();
+    --c->cpuBusy;
+    c->raysInFlight -= maxRaysPerSpawn - std::min(added, maxRaysPerSpawn);
+    putBack(c, id);
+    if (!more) c->moreRaysExist = false;
+    c->wake.notify_all();
+    return true;
+}
+
+// reference shadeRays, :92-156.
+bool shadeRays(Context* c, std::unique_lock<std::mutex>& lock, unsigned thread) {
+    if (c->readyForShade.empty() || (c->waitingToBeFilled.empty() && c->empty.empty())) return false;
+    const RenderCallbacks cb = c->currentCallbacks;
+    const uint32_t batch = c->configuration.cpuShadeBatch;
+    const uint32_t id = c->readyForShade.back();
+    c->readyForShade.pop_back();
+    RayStream* stream = &c->streams[id];
+    ++c->cpuBusy;
+    for (uint32_t start = 0; start < stream->count; start += batch) {
+        const uint32_t end = std::min(stream->count, start + batch);
+        while (c->waitingToBeFilled.empty() && c->empty.empty()) c->wake.wait(lock);   // never with the reference's stream count
+        const uint32_t outId = takeOutputStream(c);
+        RayStream* out = &c->streams[outId];
+        lock.unlock();
+        const uint32_t before = out->count;
+        cb.shade(cb.data, thread, stream, start, end, out);
+        const uint32_t added = out->count - before;
+        lock.lock();
+        c->raysInFlight += added;
+        putBack(c, outId);
+        c->wake.notify_all();
+    }
+    c->raysInFlight -= stream->count;
+    stream->count = 0;
+    c->empty.push_back(id);
+    --c->cpuBusy;
+    c->wake.notify_all();
+    return true;
+}
+
+bool finished(const Context* c) {
+    return c->shouldExit && !c->moreRaysExist && c->empty.size() == c->streams.size();
+}
+
+void cpuWorker(Context* c, unsigned thread) {   // reference cpuWorkerThread (GPU-context branch), :272-305
+    setFlushToZero();
+    std::unique_lock<std::mutex> lock(c->mutex);
+    for (;;) {
+        if (finished(c)) break;
+        if (c->currentCallbacks.spawn && spawnRays(c, lock, thread)) continue;
+        if (c->currentCallbacks.shade && shadeRays(c, lock, thread)) continue;
+        c->wake.wait(lock);
+    }
+}
+
+void gpuWorker(Context* c, unsigned lane) {   // reference gpuWorkerThread, :335-414
+    std::vector<uint32_t> ids;
+    std::vector<const void*> rays;
+    std::vector<void*> results;
+    std::vector<uint32_t> counts;
+    std::unique_lock<std::mutex> lock(c->mutex);
+    for (;;) {
+        if (finished(c)) break;
+        ids.clear();
+        if (!c->readyForTest.empty()) {
+            ids.swap(c->readyForTest);
+        } else if (!c->waitingToBeFilled.empty() && c->cpuBusy == 0 && c->readyForShade.empty() && spawnBlocked(c)) {
+            ids.swap(c->waitingToBeFilled);             // nothing on the CPU side can add rays any more: flush
+        } else {
+            c->wake.wait(lock);
+            continue;
+        }
+        rays.clear(); results.clear(); counts.clear();
+        uint64_t total = 0;
+        for (uint32_t id : ids) {
+            rays.push_back(c->streams[id].rays);
+            results.push_back(c->streams[id].results);
+            counts.push_back(c->streams[id].count);
+            total += c->streams[id].count;
+        }
+        c->rayCount += total;                            // Stats.raysTraced (reference :372)
+        ++c->gpuBusy;
+        Scene* scene = c->currentScene;
+        Environment* env = c->currentEnvironment;
+        lock.unlock();
+        const int rc = racc_hip_intersect_streams(c->hip, scene->device, env ? env->device : nullptr, uint32_t(ids.size()),
+                                                  rays.data(), results.data(), counts.data(), lane);
+        if (rc != RACC_HIP_OK) {                         // the reference ignores device errors here (:393-403); we do not
+            complainHip("GPU intersection failed");
+            std::abort();
+        }
+        lock.lock();
+        --c->gpuBusy;
+        for (uint32_t id : ids) c->readyForShade.push_back(id);
+        c->wake.notify_all();
+    }
+}
+
+}  // namespace
+
+GpuContext gpuContextForDevice(int ordinal) {
+    int n = 0;
+    if (ordinal < 0 || racc_hip_device_count(&n) != RACC_HIP_OK || ordinal >= n) return nullptr;
+    return reinterpret_cast<GpuContext>(static_cast<uintptr_t>(ordinal) + 1);
+}
+
+void init() { setFlushToZero(); }   // reference :417-423 (rtcInit has no counterpart)
+
+void deinit() {}                    // reference :425-427
+
+Configuration defaultConfiguration(GpuContext gpuContext) {   // reference :429-446, re-sized for MI355X
+    Configuration cfg{};
+    cfg.gpuContext = gpuContext;
+    cfg.allowCpuTracing = false;
+    unsigned hw = std::thread::hardware_concurrency();
+    if (!hw) hw = 1;
+    cfg.cpuThreads = std::min(hw > 2 ? hw - 2 : 1u, 32u);   // callbacks only; leave room for the submission threads
+    cfg.gpuSubmissionThreads = 2;                           // one launch + one copy in flight
+    cfg.maxRaysInFlight = 4u << 20;                         // reference 262,144 = 29 x its iGPU's 8,960 lanes; MI355X holds 327,680+
+    cfg.maxRaysPerSpawn = 128 * 128;
+    cfg.cpuTestBatch = 1024;
+    cfg.cpuShadeBatch = 8 * 1024;
+    cfg.rayStreamBatchSize = 128 * 1024;
+    return cfg;
+}
+
+Context* createContext(Configuration cfg) {
+    if (!cfg.gpuContext) {
+        complain("no GPU context given and this build has no CPU tracing mode.");
+        return nullptr;
+    }
+    if (!cfg.cpuThreads || !cfg.gpuSubmissionThreads || !cfg.rayStreamBatchSize || !cfg.maxRaysPerSpawn || !cfg.cpuShadeBatch) {
+        complain("invalid configuration (zero threads or batch sizes).");
+        return nullptr;
+    }
+    if (cfg.gpuSubmissionThreads > RACC_HIP_MAX_LANES) cfg.gpuSubmissionThreads = RACC_HIP_MAX_LANES;
+    Context* c = new (std::nothrow) Context();
+    if (!c) { complain("Unable to allocate memory."); return nullptr; }
+    c->configuration = cfg;
+
+    racc_hip_options opts{};
+    opts.struct_size = sizeof(opts);
+    opts.lanes = cfg.gpuSubmissionThreads;
+    const int device = int(reinterpret_cast<uintptr_t>(cfg.gpuContext)) - 1;
+    if (racc_hip_create(device, &opts, &c->hip) != RACC_HIP_OK) {
+        complainHip("Cannot create the GPU context");
+        delete c;
+        return nullptr;
+    }
+
+    // Stream count and size: reference :517-521.
+    const uint32_t inFlight = cfg.gpuSubmissionThreads + cfg.cpuThreads * 2;
+    c->rayStreamSize = cfg.rayStreamBatchSize + std::max(cfg.maxRaysPerSpawn, cfg.cpuShadeBatch);
+    const uint32_t streamCount = inFlight + (cfg.maxRaysInFlight + cfg.rayStreamBatchSize - 1) / cfg.rayStreamBatchSize;
+    auto up = [](size_t v) { return (v + 4095) & ~size_t(4095); };
+    const size_t perStream = up(sizeof(Ray) * size_t(c->rayStreamSize)) + up(sizeof(Result) * size_t(c->rayStreamSize));
+    c->blockBytes = perStream * streamCount;
+    if (posix_memalign(reinterpret_cast<void**>(&c->block), 4096, c->blockBytes) != 0) {
+        complain("Unable to allocate memory.");
+        racc_hip_destroy(c->hip);
+        delete c;
+        return nullptr;
+    }
+    std::memset(c->block, 0, c->blockBytes);   // ≙ the clear kernel, reference :647-698
+    // Page-lock the whole block once (one hipHostRegister over all streams).
+    c->blockPinned = racc_hip_register_host(c->hip, c->block, c->blockBytes) == RACC_HIP_OK;
+    if (!c->blockPinned) complainHip("warning: ray streams are not page-locked; PCIe copies will be staged");
+
+    c->streams.resize(streamCount);
+    size_t off = 0;
+    for (uint32_t i = 0; i < streamCount; ++i) {
+        RayStream& s = c->streams[i];
+        s.index = i;
+        s.count = 0;
+        s.rays = reinterpret_cast<Ray*>(c->block + off);
+        off += up(sizeof(Ray) * size_t(c->rayStreamSize));
+        s.results = reinterpret_cast<Result*>(c->block + off);
+        off += up(sizeof(Result) * size_t(c->rayStreamSize));
+        c->empty.push_back(i);
+    }
+    for (uint32_t i = 0; i < cfg.cpuThreads; ++i) c->threads.emplace_back(cpuWorker, c, i);
+    for (uint32_t i = 0; i < cfg.gpuSubmissionThreads; ++i) c->threads.emplace_back(gpuWorker, c, i);
+    return c;
+}
+
+void destroy(Context* c) {   // reference :761-788
+    if (!c) return;
+    {
+        std::lock_guard<std::mutex> lock(c->mutex);
+        c->shouldExit = true;
+    }
+    c->wake.notify_all();
+    for (std::thread& t : c->threads) t.join();
+    if (c->blockPinned) racc_hip_unregister_host(c->hip, c->block);
+    racc_hip_destroy(c->hip);
+    std::free(c->block);
+    delete c;
+}
+
+ContextInfo info(Context* c) {   // reference :729-736
+    ContextInfo i{};
+    i.threadCount = c->configuration.cpuThreads;
+    i.rayStreamCount = uint32_t(c->streams.size());
+    i.rayStreamSize = c->rayStreamSize;
+    i.maxRaysInFlight = c->configuration.maxRaysInFlight;
+    return i;
+}
+
+Scene* createScene(Context* c, const Vertex* vertices, unsigned vertexCount, const uint32_t* indices, unsigned indexCount) {
+    if (!c || !vertices || !indices) { complain("createScene: null argument."); return nullptr; }
+    racc_host_scene* host = nullptr;
+    if (racc_host_scene_build(&vertices->x, vertexCount, indices, indexCount, &host) != RACC_HIP_OK) {
+        complainHip("Cannot build the scene");
+        return nullptr;
+    }
+    const void *nodes = nullptr, *pairs = nullptr;
+    const uint32_t* remap = nullptr;
+    uint32_t nNodes = 0, nPairsPadded = 0, nPairs = 0, nRemap = 0;
+    racc_host_scene_blobs(host, &nodes, &nNodes, &pairs, &nPairsPadded, &nPairs, &remap, &nRemap);
+    racc_hip_scene* dev = nullptr;
+    const int rc = racc_hip_scene_upload(c->hip, nodes, nNodes, pairs, nPairsPadded, remap, nRemap, &dev);
+    racc_host_scene_free(host);
+    if (rc != RACC_HIP_OK) { complainHip("Cannot upload the scene"); return nullptr; }
+    Scene* s = new (std::nothrow) Scene{c, dev};
+    if (!s) { racc_hip_scene_free(c->hip, dev); complain("Unable to allocate memory."); }
+    return s;
+}
+
+void destroy(Scene* s) {   // reference Scene.cpp:359-372
+    if (!s) return;
+    racc_hip_scene_free(s->context->hip, s->device);
+    delete s;
+}
+
+Environment* createEnvironment(Context* c, const Color* colors, unsigned width, unsigned height) {
+    if (!c || !colors) { complain("createEnvironment: null argument."); return nullptr; }
+    racc_hip_env* dev = nullptr;
+    if (racc_hip_env_upload(c->hip, &colors->r, width, height, &dev) != RACC_HIP_OK) {
+        complainHip("Cannot upload the environment");
+        return nullptr;
+    }
+    Environment* e = new (std::nothrow) Environment{c, dev};
+    if (!e) { racc_hip_env_free(c->hip, dev); complain("Unable to allocate memory."); }
+    return e;
+}
+
+void destroy(Environment* e) {   // reference Environment.cpp:62-67
+    if (!e) return;
+    racc_hip_env_free(e->context->hip, e->device);
+    delete e;
+}
+
+Stats render(Context* c, Scene* scene, Environment* environment, RenderCallbacks callbacks) {   // reference :738-759
+    std::unique_lock<std::mutex> lock(c->mutex);
+    c->currentScene = scene;
+    c->currentEnvironment = environment;
+    c->currentCallbacks = callbacks;
+    c->moreRaysExist = true;
+    c->wake.notify_all();
+    c->wake.wait(lock, [c] { return !c->moreRaysExist && c->raysInFlight == 0 && c->cpuBusy == 0 && c->gpuBusy == 0; });
+    Stats stats{};
+    stats.raysTraced = c->rayCount;
+    c->rayCount = 0;
+    return stats;
+}
+
+}  // namespace racc

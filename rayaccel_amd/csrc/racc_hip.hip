@@ -727,6 +727,20 @@ int racc_hip_env_free(racc_hip_ctx* ctx, racc_hip_env* env) {
     return RACC_HIP_OK;
 }
 
+int racc_hip_register_host(racc_hip_ctx* ctx, void* ptr, uint64_t bytes) {
+    if (!ctx || !ptr || !bytes) return fail(RACC_HIP_ERR_INVALID, "register_host: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault), "hipHostRegister");
+    return RACC_HIP_OK;
+}
+
+int racc_hip_unregister_host(racc_hip_ctx* ctx, void* ptr) {
+    if (!ctx || !ptr) return fail(RACC_HIP_ERR_INVALID, "unregister_host: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    HIP_TRY(hipHostUnregister(ptr), "hipHostUnregister");
+    return RACC_HIP_OK;
+}
+
 int racc_hip_register_stream(racc_hip_ctx* ctx, void* rays, void* results, uint32_t capacity) {
     if (!ctx || !rays || !results || !capacity) return fail(RACC_HIP_ERR_INVALID, "register_stream: bad argument");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
@@ -771,6 +785,41 @@ int racc_hip_intersect(racc_hip_ctx* ctx, const racc_hip_scene* scene, const rac
                        const void* rays, void* results, uint32_t count, uint32_t lane) {
     if (int rc = racc_hip_intersect_async(ctx, scene, env, rays, results, count, lane)) return rc;
     return racc_hip_wait(ctx, lane);
+}
+
+int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
+                               uint32_t n_streams, const void* const* rays, void* const* results,
+                               const uint32_t* counts, uint32_t lane) {
+    if (int rc = checkLane(ctx, lane)) return rc;
+    if (!scene) return fail(RACC_HIP_ERR_INVALID, "scene is NULL");
+    if (!n_streams) return RACC_HIP_OK;
+    if (!rays || !results || !counts) return fail(RACC_HIP_ERR_INVALID, "streams: NULL array");
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        if (counts[i] && (!rays[i] || !results[i])) return fail(RACC_HIP_ERR_INVALID, "streams: NULL rays/results");
+        total += counts[i];
+    }
+    if (total > 0xFFFFFFFFull) return fail(RACC_HIP_ERR_LIMIT, "streams: more than 2^32-1 rays in one launch");
+    if (!total) return RACC_HIP_OK;
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    Lane& l = ctx->lanes[lane];
+    HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
+    if (int rc = ensureStaging(l, uint32_t(total))) return rc;
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        if (!counts[i]) continue;
+        HIP_TRY(hipMemcpyAsync(static_cast<char*>(l.dRays) + off * 32, rays[i], size_t(counts[i]) * 32, hipMemcpyHostToDevice, l.stream), "H2D rays");
+        off += counts[i];
+    }
+    if (int rc = launchTraverse(ctx, l, l.stream, scene, env, l.dRays, l.dResults, uint32_t(total))) return rc;
+    off = 0;
+    for (uint32_t i = 0; i < n_streams; ++i) {
+        if (!counts[i]) continue;
+        HIP_TRY(hipMemcpyAsync(results[i], static_cast<char*>(l.dResults) + off * 16, size_t(counts[i]) * 16, hipMemcpyDeviceToHost, l.stream), "D2H results");
+        off += counts[i];
+    }
+    HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
+    return RACC_HIP_OK;
 }
 
 int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,

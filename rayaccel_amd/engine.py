@@ -20,6 +20,7 @@ from .synth import RAY_DTYPE, RESULT_DTYPE, INVALID_TRIANGLE  # noqa: F401  (re-
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libracc_hip.so")
+API_LIB_PATH = os.path.join(_HERE, "librayaccelerator.so")       # racc:: C++ interface over the C-ABI
 CSRC = os.path.join(_HERE, "csrc")
 
 BVH2_NODE_DTYPE = np.dtype([("kind", "<u4"), ("parent", "<u4"), ("first", "<u4"), ("last", "<u4"),
@@ -68,9 +69,12 @@ ABI = {
     "racc_hip_env_free": (_i, [_vp, _vp]),
     "racc_hip_register_stream": (_i, [_vp, _vp, _vp, _u32]),
     "racc_hip_unregister_stream": (_i, [_vp, _vp, _vp]),
+    "racc_hip_register_host": (_i, [_vp, _vp, _u64]),
+    "racc_hip_unregister_host": (_i, [_vp, _vp]),
     "racc_hip_intersect": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32]),
     "racc_hip_intersect_async": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32]),
     "racc_hip_wait": (_i, [_vp, _u32]),
+    "racc_hip_intersect_streams": (_i, [_vp, _vp, _vp, _u32, _P(_vp), _P(_vp), _P(_u32), _u32]),
     "racc_hip_intersect_device": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "racc_hip_intersect_device_timed": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _P(C.c_float)]),
     "racc_hip_get_launch_info": (_i, [_vp, _u32, _P(LaunchInfo)]),
@@ -91,9 +95,11 @@ _lib = None
 
 def build_library(force=False):
     """Compile libracc_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("racc_hip.hip", "scene_build.cpp", "Makefile")]
-    srcs.append(os.path.join(_HERE, "..", "include", "racc_hip.h"))
-    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    srcs = [os.path.join(CSRC, f) for f in ("racc_hip.hip", "scene_build.cpp", "racc_api.cpp", "Makefile")]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("racc_hip.h", "RayAccelerator.h")]
+    srcs.append(os.path.join(_HERE, "..", "tests", "cpp", "render_check.cpp"))
+    outs = [LIB_PATH, API_LIB_PATH, os.path.join(_HERE, "..", "tests", "cpp", "render_check")]
+    stale = any(not os.path.exists(o) for o in outs) or any(os.path.getmtime(s) > min(os.path.getmtime(o) for o in outs) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", CSRC])
     return LIB_PATH
@@ -280,6 +286,17 @@ class Context:
             results = np.zeros(len(rays), RESULT_DTYPE)
         _check(load_library().racc_hip_intersect(self._h, scene._h, env._h if env else None, _ptr(rays), _ptr(results), len(rays), lane))
         return results
+
+    def intersect_streams(self, scene, env, ray_arrays, lane=0):
+        """Several host ray streams in ONE launch (≙ what racc::render hands the GPU thread)."""
+        n = len(ray_arrays)
+        rays = [np.ascontiguousarray(r) for r in ray_arrays]
+        outs = [np.zeros(len(r), RESULT_DTYPE) for r in rays]
+        pr = (C.c_void_p * n)(*[r.ctypes.data for r in rays])
+        po = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        cn = (C.c_uint32 * n)(*[len(r) for r in rays])
+        _check(load_library().racc_hip_intersect_streams(self._h, scene._h, env._h if env else None, n, pr, po, cn, lane))
+        return outs
 
     def intersect_device(self, scene, env, d_rays, d_results, count, lane=0, stream=None):
         _check(load_library().racc_hip_intersect_device(self._h, scene._h, env._h if env else None, d_rays, d_results, count, lane, stream))

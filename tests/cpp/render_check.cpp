@@ -1,0 +1,168 @@
+// render_check — drives racc::render (include/RayAccelerator.h) the way the reference's example app does
+// (Renderer/main.cpp:187-209,58-66; TiledRenderer.cpp:55-67): loads a reference-format scene file
+// (Renderer/main.cpp:117-191), spawns 128x128 primary-ray tiles, shades with one diffuse-ish bounce per hit up to
+// maxDepth, and dumps EVERY traced ray with its Result so the Python side can re-trace them with the oracle.
+//   render_check <scene.bin> <out.bin> <width> <height> <maxDepth> [frames]
+// Output records: {u32 pixel, u32 depth, Ray (32 B), Result (16 B)} = 56 B each, preceded by {u64 count, u64 raysTraced}.
+#include "RayAccelerator.h"
+
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+#pragma pack(push, 1)
+struct SceneHeader {   // Renderer/main.cpp:118-133
+    uint32_t maxDepth, vertexCount, triangleCount;
+    uint16_t viewportWidth, viewportHeight, environmentWidth, environmentHeight;
+    float origin[3], target[3], up[3], fov;
+};
+struct Record { uint32_t pixel, depth; float ray[8]; uint32_t triangle; float t, u, v; };
+#pragma pack(pop)
+static_assert(sizeof(SceneHeader) == 60 && sizeof(Record) == 56, "layout");
+
+struct Payload { uint32_t pixel, depth; };
+
+struct App {
+    std::vector<racc::Vertex> vertices;
+    std::vector<uint32_t> indices;
+    float camOrigin[3], camRight[3], camUp[3], camView[3];
+    unsigned width, height, tilesX, tilesY, maxDepth;
+    std::atomic<unsigned> nextTile{0};
+    racc::ContextInfo info;
+    std::vector<Payload> payload;                       // [stream][slot]
+    std::vector<std::vector<Record>> perThread;
+};
+
+void cross(const float* a, const float* b, float* r) { r[0] = a[1]*b[2]-a[2]*b[1]; r[1] = a[2]*b[0]-a[0]*b[2]; r[2] = a[0]*b[1]-a[1]*b[0]; }
+void normalize(float* v) { const float l = std::sqrt(v[0]*v[0]+v[1]*v[1]+v[2]*v[2]); v[0]/=l; v[1]/=l; v[2]/=l; }
+uint32_t hash(uint32_t x) { x = x * 747796405u + 2891336453u; uint32_t w = ((x >> ((x >> 28) + 4)) ^ x) * 277803737u; return (w >> 22) ^ w; }
+
+bool spawn(void* data, unsigned, racc::RayStream* out) {   // TiledRenderer.cpp:55-67 + Camera.cpp:55-85 (pixel centres)
+    App* app = static_cast<App*>(data);
+    const unsigned tile = app->nextTile++;
+    if (tile >= app->tilesX * app->tilesY) return false;
+    const unsigned tx = (tile % app->tilesX) * 128, ty = (tile / app->tilesX) * 128;
+    Payload* pl = app->payload.data() + size_t(out->index) * app->info.rayStreamSize;
+    for (unsigned y = 0; y < 128; ++y)
+        for (unsigned x = 0; x < 128; ++x) {
+            const float px = float(tx + x) + 0.5f, py = float(ty + y) + 0.5f;
+            float d[3];
+            for (int k = 0; k < 3; ++k) d[k] = app->camView[k] + app->camRight[k] * px + app->camUp[k] * py;
+            normalize(d);
+            racc::Ray& r = out->rays[out->count];
+            for (int k = 0; k < 3; ++k) { r.origin[k] = app->camOrigin[k]; r.dir[k] = d[k]; }
+            r.minT = 0.0f; r.maxT = 1e6f;
+            pl[out->count] = Payload{(ty + y) * app->width + tx + x, 0};
+            ++out->count;
+        }
+    return tile != app->tilesX * app->tilesY - 1;
+}
+
+void shade(void* data, unsigned thread, const racc::RayStream* in, unsigned start, unsigned end, racc::RayStream* out) {
+    App* app = static_cast<App*>(data);
+    const Payload* pin = app->payload.data() + size_t(in->index) * app->info.rayStreamSize;
+    Payload* pout = app->payload.data() + size_t(out->index) * app->info.rayStreamSize;
+    std::vector<Record>& log = app->perThread[thread];
+    for (unsigned i = start; i < end; ++i) {
+        const racc::Ray& r = in->rays[i];
+        const racc::Result& h = in->results[i];
+        Record rec;
+        rec.pixel = pin[i].pixel; rec.depth = pin[i].depth;
+        std::memcpy(rec.ray, &r, 32);
+        rec.triangle = h.triangle; rec.t = h.hit.t; rec.u = h.hit.u; rec.v = h.hit.v;
+        log.push_back(rec);
+        if (h.triangle == racc::invalidTriangle || pin[i].depth + 1 >= app->maxDepth) continue;
+        // PathTracingRenderer.cpp:410-422: o = P + 1e-4*Ng (toward the incoming side), minT = 1e-3, maxT = 1e6
+        const uint32_t* tri = &app->indices[size_t(h.triangle) * 3];
+        const racc::Vertex &a = app->vertices[tri[0]], &b = app->vertices[tri[1]], &c = app->vertices[tri[2]];
+        const float e1[3] = {b.x-a.x, b.y-a.y, b.z-a.z}, e2[3] = {c.x-a.x, c.y-a.y, c.z-a.z};
+        float n[3]; cross(e1, e2, n); normalize(n);
+        if (n[0]*r.dir[0] + n[1]*r.dir[1] + n[2]*r.dir[2] > 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+        const uint32_t h1 = hash(rec.pixel * 16u + rec.depth), h2 = hash(h1);
+        const float r1 = float(h1 >> 8) * (6.2831853f / 16777216.0f), r2 = float(h2 >> 8) * (1.0f / 16777216.0f);
+        float helper[3] = {std::fabs(n[0]) > 0.9f ? 0.f : 1.f, std::fabs(n[0]) > 0.9f ? 1.f : 0.f, 0.f}, bu[3], bv[3];
+        cross(helper, n, bu); normalize(bu); cross(n, bu, bv);
+        const float s = std::sqrt(r2), cz = std::sqrt(1.0f - r2);
+        float d[3];
+        for (int k = 0; k < 3; ++k) d[k] = n[k] * cz + (bu[k] * std::cos(r1) + bv[k] * std::sin(r1)) * s;
+        normalize(d);
+        racc::Ray& o = out->rays[out->count];
+        for (int k = 0; k < 3; ++k) { o.origin[k] = r.origin[k] + r.dir[k] * h.hit.t + 1e-4f * n[k]; o.dir[k] = d[k]; }
+        o.minT = 1e-3f; o.maxT = 1e6f;
+        pout[out->count] = Payload{rec.pixel, rec.depth + 1};
+        ++out->count;
+    }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 6) { std::fprintf(stderr, "usage: render_check scene.bin out.bin width height maxDepth [frames]\n"); return 2; }
+    App app;
+    app.width = unsigned(std::atoi(argv[3])); app.height = unsigned(std::atoi(argv[4])); app.maxDepth = unsigned(std::atoi(argv[5]));
+    const int frames = argc > 6 ? std::atoi(argv[6]) : 1;
+    app.tilesX = app.width / 128; app.tilesY = app.height / 128;   // TiledRenderer.cpp:20-22
+
+    FILE* f = std::fopen(argv[1], "rb");
+    SceneHeader hdr;
+    if (!f || std::fread(&hdr, sizeof(hdr), 1, f) != 1) { std::fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
+    app.indices.resize(size_t(hdr.triangleCount) * 3);
+    app.vertices.resize(hdr.vertexCount);
+    std::vector<racc::Color> env(size_t(hdr.environmentWidth) * hdr.environmentHeight);
+    bool ok = std::fread(app.indices.data(), 12, hdr.triangleCount, f) == hdr.triangleCount;
+    ok = ok && std::fseek(f, long(hdr.triangleCount) * (2 + 16), SEEK_CUR) == 0;                     // materials, triangle normals
+    ok = ok && std::fread(app.vertices.data(), 16, hdr.vertexCount, f) == hdr.vertexCount;
+    ok = ok && std::fseek(f, long(hdr.vertexCount) * (16 + 8), SEEK_CUR) == 0;                       // normals, texcoords
+    ok = ok && std::fread(env.data(), 16, env.size(), f) == env.size();
+    std::fclose(f);
+    if (!ok) { std::fprintf(stderr, "short scene file\n"); return 2; }
+
+    {   // Camera::lookAt, Renderer/Camera.cpp:13-26 (header.dir is the look-at TARGET, main.cpp:151)
+        float fwd[3] = {hdr.target[0]-hdr.origin[0], hdr.target[1]-hdr.origin[1], hdr.target[2]-hdr.origin[2]}, right[3], up[3];
+        normalize(fwd); cross(fwd, hdr.up, right); normalize(right); cross(right, fwd, up);
+        const float ey = std::tan(0.5f * hdr.fov * 3.14159265f / 180.0f), ex = ey * float(app.width) / float(app.height);
+        for (int k = 0; k < 3; ++k) {
+            app.camOrigin[k] = hdr.origin[k];
+            app.camRight[k] = right[k] * (-2.0f / float(app.width) * ex);
+            app.camUp[k] = up[k] * (-2.0f / float(app.height) * ey);
+            app.camView[k] = fwd[k] + right[k] * ex + up[k] * ey;
+        }
+    }
+
+    racc::init();
+    racc::GpuContext gpu = racc::gpuContextForDevice(0);
+    racc::Configuration cfg = racc::defaultConfiguration(gpu);
+    if (const char* t = std::getenv("RACC_CPU_THREADS")) cfg.cpuThreads = unsigned(std::atoi(t));
+    if (const char* t = std::getenv("RACC_BATCH")) cfg.rayStreamBatchSize = unsigned(std::atoi(t));
+    racc::Context* ctx = racc::createContext(cfg);
+    if (!ctx) return 3;
+    app.info = racc::info(ctx);
+    app.payload.resize(size_t(app.info.rayStreamCount) * app.info.rayStreamSize);
+    app.perThread.resize(app.info.threadCount);
+    racc::Scene* scene = racc::createScene(ctx, app.vertices.data(), hdr.vertexCount, app.indices.data(), hdr.triangleCount * 3);
+    racc::Environment* environment = racc::createEnvironment(ctx, env.data(), hdr.environmentWidth, hdr.environmentHeight);
+    if (!scene || !environment) return 3;
+
+    racc::RenderCallbacks cb = { &app, spawn, shade };
+    uint64_t traced = 0;
+    for (int frame = 0; frame < frames; ++frame) {
+        app.nextTile = 0;
+        for (auto& v : app.perThread) v.clear();
+        traced = racc::render(ctx, scene, environment, cb).raysTraced;
+    }
+    uint64_t count = 0;
+    for (auto& v : app.perThread) count += v.size();
+    FILE* o = std::fopen(argv[2], "wb");
+    std::fwrite(&count, 8, 1, o); std::fwrite(&traced, 8, 1, o);
+    for (auto& v : app.perThread) std::fwrite(v.data(), sizeof(Record), v.size(), o);
+    std::fclose(o);
+    std::printf("{\"raysTraced\": %llu, \"shaded\": %llu, \"streams\": %u, \"streamSize\": %u, \"threads\": %u}\n",
+                (unsigned long long)traced, (unsigned long long)count, app.info.rayStreamCount, app.info.rayStreamSize, app.info.threadCount);
+    racc::destroy(environment); racc::destroy(scene); racc::destroy(ctx); racc::deinit();
+    return count == traced ? 0 : 4;
+}
