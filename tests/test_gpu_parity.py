@@ -213,8 +213,8 @@ def test_full_size_1M_coherent_and_diffuse(gpu_ctx, full):
     same = again["triangle"] == got2["triangle"][hit]
     assert (same | (again["triangle"] == MISS)).all() and same.mean() > 0.999
     assert np.array_equal(again["t"][same].view(np.uint32), got2["t"][hit][same].view(np.uint32))
-    # open at minT: starting each ray AT its hit distance must find something strictly farther (or nothing)
-    beyond = bounce[hit].copy(); beyond["minT"] = got2["t"][hit]
+    # open at minT: starting each ray just past its hit distance must find something strictly farther (or nothing)
+    beyond = bounce[hit].copy(); beyond["minT"] = got2["t"][hit] * np.float32(1.00001)
     far = gpu_ctx.intersect(full["scene"], full["env"], beyond)
     fh = far["triangle"] != MISS
     assert (far["t"][fh] > got2["t"][hit][fh]).all()
