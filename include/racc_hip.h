@@ -49,7 +49,10 @@ typedef struct racc_hip_options {
     uint32_t refill_min;       /* idle lanes that trigger a wave refill; 0 => default */
     uint32_t leaf_min;         /* leaf-holding lanes that trigger a leaf step; 0 => default */
     uint32_t chunk;            /* rays a wave dequeues per cursor atomic; 0 => default */
-    uint32_t reserved[9];
+    uint32_t tail_active;      /* waves with <= this many live rays run both step bodies per iteration;
+                                  0 => default (16), > 64 => never */
+    uint32_t regroup_period;   /* V3 kernels: scheduling iterations between workgroup-wide regroupings; 0 => default */
+    uint32_t reserved[7];
 } racc_hip_options;
 
 typedef struct racc_hip_scene_info {
@@ -138,8 +141,10 @@ int racc_hip_intersect_device_timed(racc_hip_ctx* ctx, const racc_hip_scene* sce
 int racc_hip_get_launch_info(racc_hip_ctx* ctx, uint32_t lane, racc_hip_launch_info* info);
 /* Scheduling statistics accumulated by the debug kernel variant (kernel_variant 9) on a lane:
  * [0] inner-step iterations [1] lanes active in them [2] leaf-step iterations [3] lanes active in them
- * [4] refill iterations [5] rays loaded [6] cursor dequeues [7] waves.  Waits for the lane. */
-int racc_hip_read_stats(racc_hip_ctx* ctx, uint32_t lane, uint64_t* stats8, int reset);
+ * [4] refill iterations [5] rays loaded [6] cursor dequeues [7] waves; shader-clock cycles summed over waves:
+ * [8] inner iterations [9] of which node-fetch wait [10] leaf iterations [11] of which pair-fetch wait
+ * [12] refill iterations [13] wave lifetime; [14..15] reserved.  stats16 has 16 entries.  Waits for the lane. */
+int racc_hip_read_stats(racc_hip_ctx* ctx, uint32_t lane, uint64_t* stats16, int reset);
 
 /* Device memory helpers for hosts that do not bring their own allocator. */
 int racc_hip_malloc(racc_hip_ctx* ctx, uint64_t bytes, void** d_ptr);

@@ -48,6 +48,7 @@ struct TraverseArgs {
     const float4* nodes;      // 4 x float4 per inner node (Scene.cpp:73-78 order); the first
                               // `cacheCount` are the largest-area top of the tree (see reorderNodes)
     uint32_t cacheCount;      // nodes [0, cacheCount) are also resident in LDS
+    uint32_t nodeBytes, pairBytes;   // extents for the buffer descriptors of the V2 kernel
     const float4* pairs;      // 3 x float4 per pair (Scene.cpp:83-87 order)
     const uint32_t* remap;
     const float4* env;        // RGBA32F probe image or nullptr
@@ -59,6 +60,8 @@ struct TraverseArgs {
     uint32_t refillMin;       // idle lanes that trigger a refill
     uint32_t leafMin;         // leaf lanes that trigger a leaf step
     uint32_t maxIters;        // watchdog: a wave gives up after this many scheduling iterations
+    uint32_t regroup;         // V3: scheduling iterations between workgroup-wide regroupings
+    uint32_t tailActive;      // V2: waves with at most this many live rays run inner AND leaf bodies every iteration
     unsigned long long* stats;   // STATS builds only: [0] inner iters [1] inner lanes [2] leaf iters [3] leaf lanes
                                  //                    [4] refill iters [5] rays loaded [6] dequeues [7] waves
 };
@@ -67,16 +70,28 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
     return __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
 }
 
-// Slab test, Kernels.h:117-135.  Returns the entry distance, or tFar as the "missed" sentinel.
-__device__ __forceinline__ float aabbIntersect(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                                               float ix, float iy, float iz, float ox, float oy, float oz,
-                                               float tNear, float tFar) {
-    const float ax = __builtin_fmaf(mnx, ix, ox), bx = __builtin_fmaf(mxx, ix, ox);
-    const float ay = __builtin_fmaf(mny, iy, oy), by = __builtin_fmaf(mxy, iy, oy);
-    const float az = __builtin_fmaf(mnz, iz, oz), bz = __builtin_fmaf(mxz, iz, oz);
-    const float t0 = fmaxf(fmaxf(tNear, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
-    const float t1 = fminf(fminf(tFar, fmaxf(ax, bx)), fminf(fmaxf(ay, by), fmaxf(az, bz)));
-    return (t0 > t1) ? tFar : t0;
+// Device node record (64 B; written by reorderNodes): words 0-1 = child refs (first, last), 2-3 unused,
+//   float4 #1 = (Lmin.x, Lmax.x, Lmin.y, Lmax.y)   #2 = (Lmin.z, Lmax.z, Rmin.x, Rmax.x)   #3 = (Rmin.y, Rmax.y, Rmin.z, Rmax.z)
+// i.e. each min/max plane pair is one aligned register pair, so the six "a = fma(min, inv, ood); b = fma(max, inv, ood)"
+// of the two slab tests (Kernels.h:122-123) are six v_pk_fma_f32 instead of twelve v_fma_f32 — same IEEE results.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void slabPair(const float4 q1, const float4 q2, const float4 q3,
+                                         float ix, float iy, float iz, float ex, float ey, float ez,
+                                         float tNear, float tFar, float& tFirst, float& tLast) {
+    const f32x2 vix = {ix, ix}, viy = {iy, iy}, viz = {iz, iz}, vex = {ex, ex}, vey = {ey, ey}, vez = {ez, ez};
+    const f32x2 lx = __builtin_elementwise_fma((f32x2){q1.x, q1.y}, vix, vex);
+    const f32x2 ly = __builtin_elementwise_fma((f32x2){q1.z, q1.w}, viy, vey);
+    const f32x2 lz = __builtin_elementwise_fma((f32x2){q2.x, q2.y}, viz, vez);
+    const f32x2 rx = __builtin_elementwise_fma((f32x2){q2.z, q2.w}, vix, vex);
+    const f32x2 ry = __builtin_elementwise_fma((f32x2){q3.x, q3.y}, viy, vey);
+    const f32x2 rz = __builtin_elementwise_fma((f32x2){q3.z, q3.w}, viz, vez);
+    const float l0 = fmaxf(fmaxf(tNear, fminf(lx.x, lx.y)), fmaxf(fminf(ly.x, ly.y), fminf(lz.x, lz.y)));
+    const float l1 = fminf(fminf(tFar, fmaxf(lx.x, lx.y)), fminf(fmaxf(ly.x, ly.y), fmaxf(lz.x, lz.y)));
+    const float r0 = fmaxf(fmaxf(tNear, fminf(rx.x, rx.y)), fmaxf(fminf(ry.x, ry.y), fminf(rz.x, rz.y)));
+    const float r1 = fminf(fminf(tFar, fmaxf(rx.x, rx.y)), fminf(fmaxf(ry.x, ry.y), fmaxf(rz.x, rz.y)));
+    tFirst = (l0 > l1) ? tFar : l0;      // Kernels.h:131-134: tFar doubles as the "missed" sentinel
+    tLast = (r0 > r1) ? tFar : r0;
 }
 
 struct LaneRay {
@@ -88,10 +103,7 @@ struct LaneRay {
 };
 
 // Triangle-pair test, Kernels.h:36-115.  Updates the lane's hit and returns the new tFar.
-__device__ __forceinline__ float pairIntersect(const float4* __restrict__ pairs, uint32_t index, LaneRay& r) {
-    const float4 t0 = pairs[index * 3 + 0];
-    const float4 t1 = pairs[index * 3 + 1];
-    const float4 t2 = pairs[index * 3 + 2];
+__device__ __forceinline__ float pairIntersectData(const float4 t0, const float4 t1, const float4 t2, uint32_t index, LaneRay& r) {
     const float tNear = r.tNear, tMax = r.tFar;
 
     // n1 = e1 x e2, n2 = e3 x e1 (mad_cross, Kernels.h:23-25)
@@ -144,6 +156,10 @@ __device__ __forceinline__ float pairIntersect(const float4* __restrict__ pairs,
     r.hitU = U1 * rcp;
     r.hitV = V1 * rcp;
     return t;
+}
+
+__device__ __forceinline__ float pairIntersect(const float4* __restrict__ pairs, uint32_t index, LaneRay& r) {
+    return pairIntersectData(pairs[index * 3 + 0], pairs[index * 3 + 1], pairs[index * 3 + 2], index, r);
 }
 
 // Miss colour, Kernels.h:213-222 with OpenCL CLAMP_TO_EDGE | FILTER_LINEAR on normalized coordinates.
@@ -208,12 +224,16 @@ __global__ void __launch_bounds__(BLOCK) traverseKernel(const TraverseArgs a) {
     uint32_t wBeg = 0, wEnd = 0;        // wave's private chunk of the batch (wave-uniform)
     bool exhausted = false;             // wave-uniform: the global cursor ran past the batch
     uint32_t stInner = 0, stInnerLanes = 0, stLeaf = 0, stLeafLanes = 0, stRefill = 0, stLoaded = 0, stDeq = 0;
+    unsigned long long cyInner = 0, cyInnerLoad = 0, cyLeaf = 0, cyLeafLoad = 0, cyRefill = 0, cyStart = 0;
+    if (STATS) cyStart = __builtin_readcyclecounter();
 
     for (uint32_t iter = 0;; ++iter) {
         if (iter >= a.maxIters) {       // bounded spin: never hang the GPU on a corrupt scene
             if (lane == 0) atomicAdd(a.cursor + 2, 1u);
             break;
         }
+        unsigned long long cyTop = 0;
+        if (STATS) cyTop = __builtin_readcyclecounter();
         const uint64_t innerMask = __ballot(int(node) < 0);
         const uint64_t idleMask = __ballot(node < kLeafBase);
         const uint32_t nInner = __popcll(innerMask);
@@ -278,7 +298,7 @@ __global__ void __launch_bounds__(BLOCK) traverseKernel(const TraverseArgs a) {
                 }
             }
             wBeg += take;
-            if (STATS) stLoaded += take;
+            if (STATS) { stLoaded += take; cyRefill += __builtin_readcyclecounter() - cyTop; }
             if (exhausted && wBeg == wEnd && __ballot(rayIdx >= 0) == 0ull) break;
             continue;
         }
@@ -289,6 +309,12 @@ __global__ void __launch_bounds__(BLOCK) traverseKernel(const TraverseArgs a) {
             if (int(node) >= int(kLeafBase)) {
                 const uint32_t cur = node & 0xFFFFFFu;
                 const uint32_t cnt = node >> 24;
+                if (STATS) {   // time the pair fetch alone (perturbs the schedule; debug variant only)
+                    const unsigned long long c0 = __builtin_readcyclecounter();
+                    const float4 probe = a.pairs[cur * 3u + 2u];
+                    asm volatile("s_waitcnt vmcnt(0)" :: "v"(probe.x) : "memory");
+                    cyLeafLoad += __builtin_readcyclecounter() - c0;
+                }
                 r.tFar = pairIntersect(a.pairs, cur, r);
                 if (cnt > 1u) {
                     node = ((cnt - 1u) << 24) | (cur + 1u);
@@ -300,6 +326,7 @@ __global__ void __launch_bounds__(BLOCK) traverseKernel(const TraverseArgs a) {
                     if (sp >= uint32_t(LDS_LEVELS)) node = mySpill[size_t(sp - LDS_LEVELS) * a.spillStride];
                 }
             }
+            if (STATS) cyLeaf += __builtin_readcyclecounter() - cyTop;
         } else {
             // ---------------- inner step: two slab tests, descend nearer, push farther (Kernels.h:170-199) ----------------
             if (STATS) { ++stInner; stInnerLanes += nInner; }
@@ -311,22 +338,28 @@ __global__ void __launch_bounds__(BLOCK) traverseKernel(const TraverseArgs a) {
                     const uint32_t sw = (ni >> 2) & 3u;
                     const float4* lp = ldsNodes + ni * 4u;
                     const float4 d0 = lp[sw];
-                    kids = make_uint2(__float_as_uint(d0.z), __float_as_uint(d0.w));
+                    kids = make_uint2(__float_as_uint(d0.x), __float_as_uint(d0.y));
                     d1 = lp[1u ^ sw]; d2 = lp[2u ^ sw]; d3 = lp[3u ^ sw];
                     asm volatile("" ::: "memory");   // keep these ds_read_b128: without it the two arms are merged into flat loads
                 } else {
                     const float4* np = a.nodes + size_t(ni) * 4;
-                    kids = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(np) + 2);
+                    unsigned long long c0 = 0;
+                    if (STATS) c0 = __builtin_readcyclecounter();
+                    kids = *reinterpret_cast<const uint2*>(np);
                     d1 = np[1]; d2 = np[2]; d3 = np[3];
-                    asm volatile("" ::: "memory");
+                    asm volatile("" :: "v"(kids.x), "v"(kids.y) : "memory");   // keep the child-ref load up here, in flight with the boxes
+                    if (STATS) {
+                        asm volatile("s_waitcnt vmcnt(0)" :: "v"(d3.w), "v"(d1.x), "v"(d2.x), "v"(kids.x) : "memory");
+                        cyInnerLoad += __builtin_readcyclecounter() - c0;
+                    }
                 }
                 const float tRay = r.tFar;
-                const float tFirst = aabbIntersect(d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tNear, tRay);
-                const float tLast = aabbIntersect(d2.z, d2.w, d3.x, d3.y, d3.z, d3.w, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tNear, tRay);
+                float tFirst, tLast;
+                slabPair(d1, d2, d3, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tNear, tRay, tFirst, tLast);
                 const float firstDiff = tRay - tFirst, lastDiff = tRay - tLast;
                 if (firstDiff + lastDiff != 0.0f) {
                     const bool lastNearer = tLast < tFirst;      // signbit(tLast - tFirst), Kernels.h:193
-                    if (fmaxf(tFirst, tLast) != tRay) {
+                    if (tFirst != tRay && tLast != tRay) {   // == (fmax(tFirst,tLast) != tRay): both are <= tRay (Kernels.h:194)
                         const uint32_t far = lastNearer ? kids.x : kids.y;
                         if (sp < uint32_t(LDS_LEVELS)) myLds[sp * kBlock] = far; else mySpill[size_t(sp - LDS_LEVELS) * a.spillStride] = far;
                         ++sp;
@@ -340,6 +373,7 @@ __global__ void __launch_bounds__(BLOCK) traverseKernel(const TraverseArgs a) {
                     if (sp >= uint32_t(LDS_LEVELS)) node = mySpill[size_t(sp - LDS_LEVELS) * a.spillStride];
                 }
             }
+            if (STATS) cyInner += __builtin_readcyclecounter() - cyTop;
         }
     }
 
@@ -348,6 +382,9 @@ __global__ void __launch_bounds__(BLOCK) traverseKernel(const TraverseArgs a) {
         atomicAdd(a.stats + 2, (unsigned long long)stLeaf);  atomicAdd(a.stats + 3, (unsigned long long)stLeafLanes);
         atomicAdd(a.stats + 4, (unsigned long long)stRefill); atomicAdd(a.stats + 5, (unsigned long long)stLoaded);
         atomicAdd(a.stats + 6, (unsigned long long)stDeq);   atomicAdd(a.stats + 7, 1ull);
+        atomicAdd(a.stats + 8, cyInner); atomicAdd(a.stats + 9, cyInnerLoad); atomicAdd(a.stats + 10, cyLeaf);
+        atomicAdd(a.stats + 11, cyLeafLoad); atomicAdd(a.stats + 12, cyRefill);
+        atomicAdd(a.stats + 13, (unsigned long long)(__builtin_readcyclecounter() - cyStart));
     }
     // The last block to leave re-arms the cursor for the next launch on this lane (no host memset needed).
     __syncthreads();
@@ -357,7 +394,501 @@ __global__ void __launch_bounds__(BLOCK) traverseKernel(const TraverseArgs a) {
     }
 }
 
+// ================================================================================================ V2
+// Same algorithm and arithmetic as traverseKernel, with the per-iteration dependent chain shortened:
+//   * node / pair fetches are buffer loads (SGPR descriptor + 32-bit byte offset = ref << 6 / first * 48):
+//     no 64-bit address arithmetic on the critical path;
+//   * the stack keeps a register copy of its top entry: a pop takes the register and immediately issues the
+//     ds_read of the NEXT entry, whose latency overlaps the following iteration (LDS holds every entry, so a push
+//     never has to wait for that read);
+//   * SPILL = false instantiations (tree height <= LDS_LEVELS) have no spill branches at all;
+//   * finished rays wait for their epilogue as node == kDone; once the batch is exhausted the (expensive, divergent)
+//     epilogue runs only when >= refillMin rays are pending or the wave has nothing else to do.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t kEmpty = 0u, kDone = 1u;
+
+__device__ __forceinline__ float4 asFloat4(u32x4 v) {
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+template <int BLOCK, int LDS_LEVELS, bool SPILL, bool STATS, bool BUF = true, bool TOS = true>
+__global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) {
+    __shared__ uint32_t lds[LDS_LEVELS * BLOCK];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    uint32_t* const myLds = lds + tid;
+    uint32_t* const mySpill = a.spill + (blockIdx.x * BLOCK + tid);
+    const __amdgpu_buffer_rsrc_t nodeRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.nodes), 0, a.nodeBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pairRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.pairs), 0, a.pairBytes, 0x00020000);
+
+    LaneRay r;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = 0.0f;
+    r.ix = r.iy = r.iz = r.ex = r.ey = r.ez = 0.0f;
+    r.tNear = r.tFar = 0.0f; r.hitIndex = -1; r.hitU = r.hitV = 0.0f;
+    uint32_t rayIdx = 0;
+    uint32_t node = kEmpty;     // bit31: inner ref | >= kLeafBase: leaf, pairs pending | kDone: awaiting epilogue | kEmpty
+    uint32_t sp = 0, top = 0;   // stack height; register copy of entry sp-1
+    uint32_t wBeg = 0, wEnd = 0;
+    bool exhausted = false;
+    uint32_t stInner = 0, stInnerLanes = 0, stLeaf = 0, stLeafLanes = 0, stRefill = 0, stLoaded = 0, stDeq = 0;
+    unsigned long long cyInner = 0, cyLeaf = 0, cyRefill = 0, cyStart = 0;
+    if (STATS) cyStart = __builtin_readcyclecounter();
+
+#define RACC_PUSH(x)                                                                              \
+    do {                                                                                          \
+        const uint32_t v_ = (x);                                                                  \
+        if (!SPILL || sp < uint32_t(LDS_LEVELS)) myLds[sp * BLOCK] = v_;                          \
+        else mySpill[size_t(sp - LDS_LEVELS) * a.spillStride] = v_;                               \
+        if (TOS) top = v_;                                                                        \
+        ++sp;                                                                                     \
+    } while (0)
+#define RACC_POP_OR_DONE()                                                                        \
+    do {                                                                                          \
+        if (sp == 0u) { node = kDone; }                                                           \
+        else if (!TOS) {                                                                          \
+            --sp;                                                                                 \
+            node = myLds[(SPILL ? min(sp, uint32_t(LDS_LEVELS - 1)) : sp) * BLOCK];               \
+            if (SPILL && sp >= uint32_t(LDS_LEVELS)) node = mySpill[size_t(sp - LDS_LEVELS) * a.spillStride]; \
+        } else {                                                                                  \
+            node = top;                                                                           \
+            --sp;                                                                                 \
+            if (sp != 0u) {                                                                       \
+                const uint32_t k_ = sp - 1u;                                                      \
+                top = myLds[(SPILL ? min(k_, uint32_t(LDS_LEVELS - 1)) : k_) * BLOCK];            \
+                if (SPILL && k_ >= uint32_t(LDS_LEVELS)) top = mySpill[size_t(k_ - LDS_LEVELS) * a.spillStride]; \
+            }                                                                                     \
+        }                                                                                         \
+    } while (0)
+
+    for (uint32_t iter = 0;; ++iter) {
+        if (iter >= a.maxIters) {
+            if (lane == 0) atomicAdd(a.cursor + 2, 1u);
+            break;
+        }
+        unsigned long long cyTop = 0;
+        if (STATS) cyTop = __builtin_readcyclecounter();
+        const uint32_t nInner = __popcll(__ballot(int(node) < 0));
+        const uint32_t nLeaf = __popcll(__ballot(int(node) >= int(kLeafBase)));
+        const bool noWork = (nInner | nLeaf) == 0u;
+        bool refill = noWork;
+        if (!noWork) {
+            if (!exhausted) refill = (64u - nInner - nLeaf) >= a.refillMin;
+            else refill = uint32_t(__popcll(__ballot(node == kDone))) >= a.refillMin;
+        }
+
+        if (refill) {
+            // ---------------- batched epilogue (Kernels.h:213-241) ----------------
+            if (node == kDone) {
+                float4 out;
+                if (r.hitIndex < 0) {
+                    // Miss: park the (clamped) direction in the rgb slots; envShadeKernel turns it into radiance right after
+                    // this kernel on the same stream.  Keeps acosf + bilinear (~130 divergent instructions) out of the hot loop.
+                    out = a.env ? make_float4(__uint_as_float(kInvalidTriangle), r.dx, r.dy, r.dz)
+                                : make_float4(__uint_as_float(kInvalidTriangle), 0.0f, 0.0f, 0.0f);
+                } else {
+                    uint32_t m = a.remap[r.hitIndex];
+                    const uint32_t edge = m >> 30;
+                    m &= 0x3FFFFFFFu;
+                    const float bx = r.hitU, by = r.hitV, bz = 1.0f - r.hitU - r.hitV;
+                    float u = bx, v = by;
+                    if (edge == 1u) { u = bz; v = bx; } else if (edge == 2u) { u = by; v = bz; }
+                    out = make_float4(__uint_as_float(m), r.tFar, u, v);
+                }
+                a.results[rayIdx] = out;
+                node = kEmpty;
+            }
+            // ---------------- refill: ballot + mbcnt prefix sum over the empty lanes ----------------
+            const uint64_t emptyMask = __ballot(node == kEmpty);
+            const uint32_t need = __popcll(emptyMask);
+            if (STATS) ++stRefill;
+            if (wBeg == wEnd && !exhausted) {
+                if (STATS) ++stDeq;
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(a.cursor, a.chunk);
+                b = __builtin_amdgcn_readfirstlane(b);
+                wBeg = min(b, a.count);
+                wEnd = min(b + a.chunk, a.count);
+                exhausted = (b >= a.count) || (b + a.chunk < b);
+            }
+            const uint32_t take = min(need, wEnd - wBeg);
+            const uint32_t rank = laneRank(emptyMask);
+            if (node == kEmpty && rank < take) {
+                const uint32_t idx = wBeg + rank;
+                const float4 q0 = a.rays[size_t(idx) * 2 + 0];
+                const float4 q1 = a.rays[size_t(idx) * 2 + 1];
+                const bool valid = isfinite(q0.x) && isfinite(q0.y) && isfinite(q0.z) && isfinite(q0.w) &&
+                                   isfinite(q1.x) && isfinite(q1.y) && isfinite(q1.z) && !isnan(q1.w);
+                if (!valid) {   // NaN in the first slot tells envShadeKernel to leave rgb = 0
+                    a.results[idx] = make_float4(__uint_as_float(kInvalidTriangle), a.env ? __uint_as_float(0x7FC00000u) : 0.0f, 0.0f, 0.0f);
+                } else {
+                    const float eps = 1e-10f;   // Kernels.h:149-157
+                    r.ox = q0.x; r.oy = q0.y; r.oz = q0.z; r.tNear = q0.w;
+                    r.dx = (fabsf(q1.x) < eps) ? copysignf(eps, q1.x) : q1.x;
+                    r.dy = (fabsf(q1.y) < eps) ? copysignf(eps, q1.y) : q1.y;
+                    r.dz = (fabsf(q1.z) < eps) ? copysignf(eps, q1.z) : q1.z;
+                    r.tFar = q1.w;
+                    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;    // Kernels.h:159-160
+                    r.ex = -r.ox * r.ix; r.ey = -r.oy * r.iy; r.ez = -r.oz * r.iz;
+                    r.hitIndex = -1; r.hitU = 0.0f; r.hitV = 0.0f;
+                    rayIdx = idx;
+                    node = 0x80000000u;     // Kernels.h:164
+                    sp = 0;
+                }
+            }
+            wBeg += take;
+            if (STATS) { stLoaded += take; cyRefill += __builtin_readcyclecounter() - cyTop; }
+            if (exhausted && wBeg == wEnd && __ballot(node != kEmpty) == 0ull) break;
+            continue;
+        }
+
+        // Vote: a leaf step when enough lanes wait at a leaf — `leafMin` of them in a full wave, a quarter of the active
+        // lanes in a thin one (the launch tail, where a lone long ray must not idle behind the vote) — or when no lane
+        // holds an inner node.  Thin waves (<= tailActive rays) run both bodies per iteration: they are latency-bound.
+        const uint32_t nActive = nInner + nLeaf;
+        const bool doLeaf = nLeaf >= a.leafMin || nInner == 0u || nLeaf * 4u >= nActive;
+        const bool doInner = nInner != 0u && (!doLeaf || nActive <= a.tailActive);
+        if (doLeaf) {
+            // ---------------- leaf step (Kernels.h:200-205 + 36-115) ----------------
+            if (STATS) { ++stLeaf; stLeafLanes += nLeaf; }
+            if (int(node) >= int(kLeafBase)) {
+                const uint32_t cur = node & 0xFFFFFFu;
+                const uint32_t cnt = node >> 24;
+                const uint32_t off = cur * 48u;
+                float4 t0, t1, t2;
+                if (BUF) {
+                    t0 = asFloat4(__builtin_amdgcn_raw_buffer_load_b128(pairRsrc, off, 0, 0));
+                    t1 = asFloat4(__builtin_amdgcn_raw_buffer_load_b128(pairRsrc, off + 16u, 0, 0));
+                    t2 = asFloat4(__builtin_amdgcn_raw_buffer_load_b128(pairRsrc, off + 32u, 0, 0));
+                } else {
+                    t0 = a.pairs[cur * 3u]; t1 = a.pairs[cur * 3u + 1u]; t2 = a.pairs[cur * 3u + 2u];
+                }
+                r.tFar = pairIntersectData(t0, t1, t2, cur, r);
+                if (cnt > 1u) node = ((cnt - 1u) << 24) | (cur + 1u);
+                else RACC_POP_OR_DONE();
+            }
+            if (STATS) { cyLeaf += __builtin_readcyclecounter() - cyTop; cyTop = __builtin_readcyclecounter(); }
+        }
+        if (doInner) {
+            // ---------------- inner step (Kernels.h:170-199 + 117-135) ----------------
+            if (STATS) { ++stInner; stInnerLanes += nInner; }
+            if (int(node) < 0) {
+                const uint32_t off = node << 6;             // bit 31 falls off: byte offset of the 64 B record
+                u32x2 kids;
+                float4 d1, d2, d3;
+                if (BUF) {
+                    kids = __builtin_amdgcn_raw_buffer_load_b64(nodeRsrc, off, 0, 0);
+                    d1 = asFloat4(__builtin_amdgcn_raw_buffer_load_b128(nodeRsrc, off + 16u, 0, 0));
+                    d2 = asFloat4(__builtin_amdgcn_raw_buffer_load_b128(nodeRsrc, off + 32u, 0, 0));
+                    d3 = asFloat4(__builtin_amdgcn_raw_buffer_load_b128(nodeRsrc, off + 48u, 0, 0));
+                } else {
+                    const float4* np = a.nodes + size_t(node & 0x7FFFFFFFu) * 4;
+                    const uint2 k2 = *reinterpret_cast<const uint2*>(np);
+                    d1 = np[1]; d2 = np[2]; d3 = np[3];
+                    asm volatile("" :: "v"(k2.x), "v"(k2.y));   // keep the child-ref load up here, in flight with the boxes (the
+                    kids.x = k2.x; kids.y = k2.y;               // compiler otherwise sinks it behind the slab tests: +1 round trip)
+                }
+                const float tRay = r.tFar;
+                float tFirst, tLast;
+                slabPair(d1, d2, d3, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tNear, tRay, tFirst, tLast);
+                const float firstDiff = tRay - tFirst, lastDiff = tRay - tLast;
+                if (firstDiff + lastDiff != 0.0f) {
+                    const bool lastNearer = tLast < tFirst;      // signbit(tLast - tFirst), Kernels.h:193
+                    if (tFirst != tRay && tLast != tRay) RACC_PUSH(lastNearer ? kids.x : kids.y);
+                    node = lastNearer ? kids.y : kids.x;
+                } else {
+                    RACC_POP_OR_DONE();
+                }
+            }
+            if (STATS) cyInner += __builtin_readcyclecounter() - cyTop;
+        }
+    }
+#undef RACC_PUSH
+#undef RACC_POP_OR_DONE
+
+    if (STATS && lane == 0) {
+        atomicAdd(a.stats + 0, (unsigned long long)stInner); atomicAdd(a.stats + 1, (unsigned long long)stInnerLanes);
+        atomicAdd(a.stats + 2, (unsigned long long)stLeaf);  atomicAdd(a.stats + 3, (unsigned long long)stLeafLanes);
+        atomicAdd(a.stats + 4, (unsigned long long)stRefill); atomicAdd(a.stats + 5, (unsigned long long)stLoaded);
+        atomicAdd(a.stats + 6, (unsigned long long)stDeq);   atomicAdd(a.stats + 7, 1ull);
+        atomicAdd(a.stats + 8, cyInner); atomicAdd(a.stats + 10, cyLeaf); atomicAdd(a.stats + 12, cyRefill);
+        atomicAdd(a.stats + 13, (unsigned long long)(__builtin_readcyclecounter() - cyStart));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t prev = atomicInc(a.cursor + 1, gridDim.x - 1);
+        if (prev == gridDim.x - 1) atomicExch(a.cursor, 0u);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host side
+
+// ================================================================================================ V3
+// Workgroup-wide ballot/prefix-sum compaction.  V1/V2 keep a ray in the lane that loaded it, so a wave is a mix of
+// lanes that hold an inner node, lanes that wait at a leaf and lanes that wait for a refill: measured lane utilisation
+// 66 % in inner steps and 15 % in leaf steps even in steady state (profiles/).  Here the WAVES waves of a workgroup
+// re-deal their rays every `regroup` scheduling iterations: each ray is classified (inner / leaf / finished / empty
+// lane), a counting sort over the whole workgroup (wave ballots + mbcnt ranks + one 64-lane scan of the per-wave
+// counts) gives every ray a new lane so that each wave holds ONE kind of work, and the per-ray state — kept as a
+// [field][slot] structure-of-arrays record in LDS next to its [level][slot] stack — is re-read by its new lane.
+// Inner waves then run the slab-test body with ~all lanes live, the leaf wave runs the pair test with ~all lanes
+// live, finished rays get their epilogue together and empty lanes refill together.  A ray's arithmetic and the order
+// of its own steps are untouched, so results stay bit-identical to the oracle.
+//   LDS per workgroup: (LDS_LEVELS + 20 + 1) * T * 4 B  (T = 64 * WAVES): 74 KiB at T = 512 -> two workgroups per CU.
+constexpr int kRecFields = 20;   // o[3] d[3] inv[3] ood[3] tNear rayIdx | node sp tFar hitIndex hitU hitV
+
+template <int WAVES, int LDS_LEVELS, bool SPILL, bool STATS>
+__global__ void __launch_bounds__(WAVES * 64) traverseKernelV3(const TraverseArgs a) {
+    constexpr int T = WAVES * 64;
+    static_assert(WAVES <= 16, "the regroup scan keeps 4 x WAVES counters in one wave");
+    __shared__ uint32_t lds[LDS_LEVELS * T + kRecFields * T + T + 64 + 4];
+    uint32_t* const stackBase = lds;                               // [level][slot]
+    uint32_t* const rec = lds + LDS_LEVELS * T;                    // [field][slot]
+    uint32_t* const perm = rec + kRecFields * T;                   // [lane of the workgroup] -> slot
+    uint32_t* const waveCount = perm + T;                          // [kind][wave], 4 x WAVES <= 64 words
+    uint32_t* const wgFlags = waveCount + 64;                      // [0] batch exhausted
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    LaneRay r;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = 0.0f;
+    r.ix = r.iy = r.iz = r.ex = r.ey = r.ez = 0.0f;
+    r.tNear = r.tFar = 0.0f; r.hitIndex = -1; r.hitU = r.hitV = 0.0f;
+    uint32_t rayIdx = 0;
+    uint32_t node = kEmpty;
+    uint32_t sp = 0;
+    uint32_t slot = tid;                 // which stack column / record this lane's ray owns; travels with the ray
+    uint32_t wBeg = 0, wEnd = 0;
+    bool exhausted = false;
+    uint32_t stInner = 0, stInnerLanes = 0, stLeaf = 0, stLeafLanes = 0, stRefill = 0, stLoaded = 0, stDeq = 0, stShuffle = 0;
+    unsigned long long cyInner = 0, cyLeaf = 0, cyRefill = 0, cyShuffle = 0, cyStart = 0;
+    if (STATS) cyStart = __builtin_readcyclecounter();
+
+    if (tid == 0) wgFlags[0] = 0u;
+    __syncthreads();
+
+#define RACC3_PUSH(val_)                                                                          \
+    do {                                                                                          \
+        const uint32_t pv_ = (val_);                                                              \
+        if (!SPILL || sp < uint32_t(LDS_LEVELS)) stackBase[sp * T + slot] = pv_;                  \
+        else a.spill[size_t(sp - LDS_LEVELS) * a.spillStride + blockIdx.x * T + slot] = pv_;      \
+        ++sp;                                                                                     \
+    } while (0)
+#define RACC3_POP_OR_DONE()                                                                       \
+    do {                                                                                          \
+        if (sp == 0u) { node = kDone; }                                                           \
+        else {                                                                                    \
+            --sp;                                                                                 \
+            node = stackBase[(SPILL ? min(sp, uint32_t(LDS_LEVELS - 1)) : sp) * T + slot];        \
+            if (SPILL && sp >= uint32_t(LDS_LEVELS))                                              \
+                node = a.spill[size_t(sp - LDS_LEVELS) * a.spillStride + blockIdx.x * T + slot];  \
+        }                                                                                         \
+    } while (0)
+
+    for (uint32_t round = 0;; ++round) {
+        if (round >= (a.maxIters >> 4)) {   // bounded: never hang the GPU (uniform across the workgroup)
+            if (tid == 0) atomicAdd(a.cursor + 2, 1u);
+            break;
+        }
+        // ------------------------------------------------ up to `regroup` scheduling iterations, wave-private
+        for (uint32_t it = 0; it < a.regroup; ++it) {
+            unsigned long long cyTop = 0;
+            if (STATS) cyTop = __builtin_readcyclecounter();
+            const uint32_t nInner = __popcll(__ballot(int(node) < 0));
+            const uint32_t nLeaf = __popcll(__ballot(int(node) >= int(kLeafBase)));
+            const bool noWork = (nInner | nLeaf) == 0u;
+            bool refill = noWork;
+            if (!noWork) {
+                if (!exhausted) refill = (64u - nInner - nLeaf) >= a.refillMin;
+                else refill = uint32_t(__popcll(__ballot(node == kDone))) >= a.refillMin;
+            }
+            if (refill) {
+                if (node == kDone) {       // ---- batched epilogue (Kernels.h:223-239; misses: see envShadeKernel)
+                    float4 out;
+                    if (r.hitIndex < 0) {
+                        out = a.env ? make_float4(__uint_as_float(kInvalidTriangle), r.dx, r.dy, r.dz)
+                                    : make_float4(__uint_as_float(kInvalidTriangle), 0.0f, 0.0f, 0.0f);
+                    } else {
+                        uint32_t m = a.remap[r.hitIndex];
+                        const uint32_t edge = m >> 30;
+                        m &= 0x3FFFFFFFu;
+                        const float bx = r.hitU, by = r.hitV, bz = 1.0f - r.hitU - r.hitV;
+                        float u = bx, v = by;
+                        if (edge == 1u) { u = bz; v = bx; } else if (edge == 2u) { u = by; v = bz; }
+                        out = make_float4(__uint_as_float(m), r.tFar, u, v);
+                    }
+                    a.results[rayIdx] = out;
+                    node = kEmpty;
+                }
+                const uint64_t emptyMask = __ballot(node == kEmpty);
+                const uint32_t need = __popcll(emptyMask);
+                if (STATS) ++stRefill;
+                if (wBeg == wEnd && !exhausted) {
+                    if (STATS) ++stDeq;
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(a.cursor, a.chunk);
+                    b = __builtin_amdgcn_readfirstlane(b);
+                    wBeg = min(b, a.count);
+                    wEnd = min(b + a.chunk, a.count);
+                    exhausted = (b >= a.count) || (b + a.chunk < b);
+                    if (exhausted && lane == 0) wgFlags[0] = 1u;
+                }
+                const uint32_t take = min(need, wEnd - wBeg);
+                const uint32_t rank = laneRank(emptyMask);
+                if (node == kEmpty && rank < take) {
+                    const uint32_t idx = wBeg + rank;
+                    const float4 q0 = a.rays[size_t(idx) * 2 + 0];
+                    const float4 q1 = a.rays[size_t(idx) * 2 + 1];
+                    const bool valid = isfinite(q0.x) && isfinite(q0.y) && isfinite(q0.z) && isfinite(q0.w) &&
+                                       isfinite(q1.x) && isfinite(q1.y) && isfinite(q1.z) && !isnan(q1.w);
+                    if (!valid) {
+                        a.results[idx] = make_float4(__uint_as_float(kInvalidTriangle), a.env ? __uint_as_float(0x7FC00000u) : 0.0f, 0.0f, 0.0f);
+                    } else {
+                        const float eps = 1e-10f;   // Kernels.h:149-157
+                        r.ox = q0.x; r.oy = q0.y; r.oz = q0.z; r.tNear = q0.w;
+                        r.dx = (fabsf(q1.x) < eps) ? copysignf(eps, q1.x) : q1.x;
+                        r.dy = (fabsf(q1.y) < eps) ? copysignf(eps, q1.y) : q1.y;
+                        r.dz = (fabsf(q1.z) < eps) ? copysignf(eps, q1.z) : q1.z;
+                        r.tFar = q1.w;
+                        r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;    // Kernels.h:159-160
+                        r.ex = -r.ox * r.ix; r.ey = -r.oy * r.iy; r.ez = -r.oz * r.iz;
+                        r.hitIndex = -1; r.hitU = 0.0f; r.hitV = 0.0f;
+                        rayIdx = idx;
+                        node = 0x80000000u;     // Kernels.h:164
+                        sp = 0;
+                        // The immutable part of the record is written once, here; regrouping re-reads it by slot.
+                        uint32_t* rp = rec + slot;
+                        rp[0 * T] = __float_as_uint(r.ox); rp[1 * T] = __float_as_uint(r.oy); rp[2 * T] = __float_as_uint(r.oz);
+                        rp[3 * T] = __float_as_uint(r.dx); rp[4 * T] = __float_as_uint(r.dy); rp[5 * T] = __float_as_uint(r.dz);
+                        rp[6 * T] = __float_as_uint(r.ix); rp[7 * T] = __float_as_uint(r.iy); rp[8 * T] = __float_as_uint(r.iz);
+                        rp[9 * T] = __float_as_uint(r.ex); rp[10 * T] = __float_as_uint(r.ey); rp[11 * T] = __float_as_uint(r.ez);
+                        rp[12 * T] = __float_as_uint(r.tNear); rp[13 * T] = rayIdx;
+                    }
+                }
+                wBeg += take;
+                if (STATS) { stLoaded += take; cyRefill += __builtin_readcyclecounter() - cyTop; }
+                if (exhausted && wBeg == wEnd && __ballot(node != kEmpty) == 0ull) break;   // this wave is dry: go regroup
+                continue;
+            }
+
+            const uint32_t nActive = nInner + nLeaf;
+            const bool thin = nActive <= a.tailActive;
+            const bool doLeaf = nLeaf >= a.leafMin || nInner == 0u || (thin && nLeaf * 4u >= nActive);
+            const bool doInner = nInner != 0u && (!doLeaf || thin);
+            if (doLeaf) {
+                if (STATS) { ++stLeaf; stLeafLanes += nLeaf; }
+                if (int(node) >= int(kLeafBase)) {      // ---- leaf step (Kernels.h:200-205 + 36-115)
+                    const uint32_t cur = node & 0xFFFFFFu;
+                    const uint32_t cnt = node >> 24;
+                    r.tFar = pairIntersectData(a.pairs[cur * 3u], a.pairs[cur * 3u + 1u], a.pairs[cur * 3u + 2u], cur, r);
+                    if (cnt > 1u) node = ((cnt - 1u) << 24) | (cur + 1u);
+                    else RACC3_POP_OR_DONE();
+                }
+                if (STATS) { cyLeaf += __builtin_readcyclecounter() - cyTop; cyTop = __builtin_readcyclecounter(); }
+            }
+            if (doInner) {
+                if (STATS) { ++stInner; stInnerLanes += nInner; }
+                if (int(node) < 0) {                    // ---- inner step (Kernels.h:170-199 + 117-135)
+                    const float4* np = a.nodes + size_t(node & 0x7FFFFFFFu) * 4;
+                    const uint2 kids = *reinterpret_cast<const uint2*>(np);
+                    const float4 d1 = np[1], d2 = np[2], d3 = np[3];
+                    asm volatile("" :: "v"(kids.x), "v"(kids.y));   // keep the child-ref load up here, in flight with the boxes
+                    const float tRay = r.tFar;
+                    float tFirst, tLast;
+                    slabPair(d1, d2, d3, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tNear, tRay, tFirst, tLast);
+                    const float firstDiff = tRay - tFirst, lastDiff = tRay - tLast;
+                    if (firstDiff + lastDiff != 0.0f) {
+                        const bool lastNearer = tLast < tFirst;      // signbit(tLast - tFirst), Kernels.h:193
+                        if (tFirst != tRay && tLast != tRay) RACC3_PUSH(lastNearer ? kids.x : kids.y);
+                        node = lastNearer ? kids.y : kids.x;
+                    } else {
+                        RACC3_POP_OR_DONE();
+                    }
+                }
+                if (STATS) cyInner += __builtin_readcyclecounter() - cyTop;
+            }
+        }
+
+        // ------------------------------------------------ regroup: counting sort of the workgroup's rays by kind
+        unsigned long long cySh = 0;
+        if (STATS) { cySh = __builtin_readcyclecounter(); ++stShuffle; }
+        const uint32_t kind = (int(node) < 0) ? 0u : (node >= kLeafBase) ? 1u : (node == kDone) ? 2u : 3u;
+        const uint64_t m0 = __ballot(kind == 0u), m1 = __ballot(kind == 1u), m2 = __ballot(kind == 2u), m3 = __ballot(kind == 3u);
+        const uint64_t mine = kind == 0u ? m0 : kind == 1u ? m1 : kind == 2u ? m2 : m3;
+        const uint32_t rankInWave = laneRank(mine);
+        // No barrier is needed here: a wave only rewrites the records of slots it owns, the per-wave counters are last
+        // read before B3 of the previous regroup, and `perm` is rewritten only after B2 of this one.
+        if (lane < 4u) {
+            const uint64_t mk = lane == 0u ? m0 : lane == 1u ? m1 : lane == 2u ? m2 : m3;
+            waveCount[lane * WAVES + wave] = uint32_t(__popcll(mk));
+        }
+        {   // mutable part of the record
+            uint32_t* rp = rec + slot;
+            rp[14 * T] = node; rp[15 * T] = sp; rp[16 * T] = __float_as_uint(r.tFar);
+            rp[17 * T] = uint32_t(r.hitIndex); rp[18 * T] = __float_as_uint(r.hitU); rp[19 * T] = __float_as_uint(r.hitV);
+        }
+        __syncthreads();                                   // B1: counts and records visible
+        // One 64-lane exclusive scan of the (kind-major) counter table gives, at entry kind*WAVES + wave, the first
+        // destination lane of that wave's rays of that kind.
+        uint32_t cntHere = (lane < 4u * WAVES) ? waveCount[lane] : 0u;
+        uint32_t incl = cntHere;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= uint32_t(d)) incl += up;
+        }
+        const uint32_t excl = incl - cntHere;
+        const uint32_t destBase = __shfl(excl, int(kind * WAVES + wave));
+        const uint32_t liveRays = __builtin_amdgcn_readfirstlane(__shfl(excl, 3 * WAVES));   // inner + leaf + finished, whole workgroup
+        perm[destBase + rankInWave] = slot;
+        exhausted = exhausted || (wgFlags[0] != 0u);
+        __syncthreads();                                   // B2: permutation complete
+        slot = perm[tid];
+        {
+            const uint32_t* rp = rec + slot;
+            r.ox = __uint_as_float(rp[0 * T]); r.oy = __uint_as_float(rp[1 * T]); r.oz = __uint_as_float(rp[2 * T]);
+            r.dx = __uint_as_float(rp[3 * T]); r.dy = __uint_as_float(rp[4 * T]); r.dz = __uint_as_float(rp[5 * T]);
+            r.ix = __uint_as_float(rp[6 * T]); r.iy = __uint_as_float(rp[7 * T]); r.iz = __uint_as_float(rp[8 * T]);
+            r.ex = __uint_as_float(rp[9 * T]); r.ey = __uint_as_float(rp[10 * T]); r.ez = __uint_as_float(rp[11 * T]);
+            r.tNear = __uint_as_float(rp[12 * T]); rayIdx = rp[13 * T];
+            node = rp[14 * T]; sp = rp[15 * T]; r.tFar = __uint_as_float(rp[16 * T]);
+            r.hitIndex = int(rp[17 * T]); r.hitU = __uint_as_float(rp[18 * T]); r.hitV = __uint_as_float(rp[19 * T]);
+        }
+        if (STATS) cyShuffle += __builtin_readcyclecounter() - cySh;
+        // Workgroup-uniform exit: `exhausted` was re-read from the shared flag between B1 and B2 (no wave can write it
+        // there), liveRays comes from the shared counters.  A wave that still owns undealt rays of its chunk always holds
+        // live rays (it refills whenever it has nothing else to do), so liveRays == 0 also means no chunk is pending.
+        if (liveRays == 0u && exhausted) break;
+    }
+#undef RACC3_PUSH
+#undef RACC3_POP_OR_DONE
+
+    if (STATS && lane == 0) {
+        atomicAdd(a.stats + 0, (unsigned long long)stInner); atomicAdd(a.stats + 1, (unsigned long long)stInnerLanes);
+        atomicAdd(a.stats + 2, (unsigned long long)stLeaf);  atomicAdd(a.stats + 3, (unsigned long long)stLeafLanes);
+        atomicAdd(a.stats + 4, (unsigned long long)stRefill); atomicAdd(a.stats + 5, (unsigned long long)stLoaded);
+        atomicAdd(a.stats + 6, (unsigned long long)stDeq);   atomicAdd(a.stats + 7, 1ull);
+        atomicAdd(a.stats + 8, cyInner); atomicAdd(a.stats + 10, cyLeaf); atomicAdd(a.stats + 12, cyRefill);
+        atomicAdd(a.stats + 13, (unsigned long long)(__builtin_readcyclecounter() - cyStart));
+        atomicAdd(a.stats + 14, cyShuffle); atomicAdd(a.stats + 15, (unsigned long long)stShuffle);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t prev = atomicInc(a.cursor + 1, gridDim.x - 1);
+        if (prev == gridDim.x - 1) atomicExch(a.cursor, 0u);
+    }
+}
+
+// Second (tiny, streaming) kernel of the V2 path: every miss record holds the ray direction; replace it by the
+// probe-image radiance (Kernels.h:213-222).  16 B read per ray, 16 B written per miss.
+__global__ void __launch_bounds__(256) envShadeKernel(float4* results, uint32_t count, const float4* env, uint32_t envW, uint32_t envH) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const float4 rec = results[i];
+        if (__float_as_uint(rec.x) != kInvalidTriangle) continue;
+        results[i] = isnan(rec.y) ? make_float4(rec.x, 0.0f, 0.0f, 0.0f) : envSample(env, envW, envH, rec.y, rec.z, rec.w);
+    }
+}
 
 thread_local char g_msg[512];
 
@@ -384,6 +915,7 @@ struct Lane {
     uint32_t capacity = 0;
     std::vector<hipEvent_t> events;
     racc_hip_launch_info info{};
+    bool pendingEnv = false;             // last traversal launch parked miss directions (V2): envShade must follow
 };
 
 }  // namespace
@@ -479,10 +1011,14 @@ void reorderNodes(const GpuNodeHost* in, uint32_t n, std::vector<GpuNodeHost>& o
     for (uint32_t i = 0; i < n; ++i) oldToNew[newToOld[i]] = i;
     out.resize(n);
     for (uint32_t i = 0; i < n; ++i) {
-        GpuNodeHost g = in[newToOld[i]];
-        if (g.first & 0x80000000u) g.first = 0x80000000u | oldToNew[g.first & 0x7FFFFFFFu];
-        if (g.last & 0x80000000u) g.last = 0x80000000u | oldToNew[g.last & 0x7FFFFFFFu];
-        out[i] = g;
+        const GpuNodeHost& g = in[newToOld[i]];
+        GpuNodeHost d{};   // device record: see slabPair
+        d.kind = (g.first & 0x80000000u) ? (0x80000000u | oldToNew[g.first & 0x7FFFFFFFu]) : g.first;      // word 0: first child
+        d.parent = (g.last & 0x80000000u) ? (0x80000000u | oldToNew[g.last & 0x7FFFFFFFu]) : g.last;        // word 1: last child
+        const float* b = g.box;   // leftMin[3], leftMax[3], rightMin[3], rightMax[3]
+        const float planes[12] = { b[0], b[3], b[1], b[4], b[2], b[5], b[6], b[9], b[7], b[10], b[8], b[11] };
+        std::memcpy(d.box, planes, sizeof(planes));
+        out[i] = d;
     }
 }
 
@@ -501,6 +1037,9 @@ uint32_t optOr(uint32_t v, uint32_t dflt) { return v ? v : dflt; }
 struct Variant {
     int block, ldsLevels, cacheNodes;
     void (*kernel)(const TraverseArgs);
+    bool noSpill = false;      // kernel has no global spill path: only valid while tree height <= ldsLevels
+    bool deferEnv = false;     // kernel parks miss directions; envShadeKernel must follow
+    int stackLevels() const { return ldsLevels > 32 ? ldsLevels - (kRecFields + 1) : ldsLevels; }   // V3 rows fold the record words into ldsLevels
 };
 // kernel_variant n selects kVariants[n-1]; 0 selects kDefaultVariant.  LDS per workgroup = cacheNodes*64 + ldsLevels*block*4.
 const Variant kVariants[] = {
@@ -513,21 +1052,44 @@ const Variant kVariants[] = {
     {1024, 12, 1024, traverseKernel<1024, 12, 1024>},  // 7: 112 KiB: 64 + 48
     {512, 12, 1024, traverseKernel<512, 12, 1024>},    // 8: 88 KiB: 64 + 24, 1 WG/CU
     {256, 16, 0, traverseKernel<256, 16, 0, true>},    // 9: variant 1 + scheduling statistics (debug)
+    {256, 32, 0, traverseKernelV2<256, 32, false, false>, true, true},   // 10: V2, 32 LDS levels, no spill path (height <= 32)
+    {256, 16, 0, traverseKernelV2<256, 16, true, false>, false, true},    // 11: V2, 16 LDS levels + global spill (any height)
+    {256, 32, 0, traverseKernelV2<256, 32, false, true>, true, true},    // 12: variant 10 + statistics (debug)
+    {256, 24, 0, traverseKernelV2<256, 24, true, false>, false, true},    // 13: V2, 24 LDS levels + spill
+    {256, 32, 0, traverseKernelV2<256, 32, false, false, false, false>, true, true},   // 14: V2 ablation: global loads, no top-of-stack register
+    {256, 32, 0, traverseKernelV2<256, 32, false, false, true, false>, true, true},    // 15: V2 ablation: buffer loads only
+    {256, 32, 0, traverseKernelV2<256, 32, false, false, false, true>, true, true},    // 16: V2 ablation: top-of-stack register only
+    {256, 16, 0, traverseKernelV2<256, 16, true, false, false, false>, false, true},          // 17: V2 ablation: 16 levels + spill, neither
+    {512, 16 + kRecFields + 1, 0, traverseKernelV3<8, 16, true, false>, false, true},      // 18: V3, 8-wave workgroups (2 per CU)
+    {1024, 16 + kRecFields + 1, 0, traverseKernelV3<16, 16, true, false>, false, true},    // 19: V3, 16-wave workgroups (1 per CU)
+    {256, 16 + kRecFields + 1, 0, traverseKernelV3<4, 16, true, false>, false, true},      // 20: V3, 4-wave workgroups (4 per CU)
+    {512, 16 + kRecFields + 1, 0, traverseKernelV3<8, 16, true, true>, false, true},       // 21: variant 18 + statistics (debug)
+    {256, 26, 0, traverseKernelV2<256, 26, false, false, false, false>, true, true},       // 22: V2, 26 LDS levels, no spill path (26 KiB: 6 WG/CU)
+    {256, 28, 0, traverseKernelV2<256, 28, false, false, false, false>, true, true},       // 23: V2, 28 LDS levels, no spill path (28 KiB: 5 WG/CU)
+    {256, 30, 0, traverseKernelV2<256, 30, false, false, false, false>, true, true},       // 24: V2, 30 LDS levels, no spill path
 };
 constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
-constexpr int kDefaultVariant = 1;
+constexpr int kSpillFallback = 17;    // V2 with 16 LDS levels + global spill: used when a tree is taller than a variant's LDS stack
 constexpr uint32_t kLdsPerCU = 160u * 1024u;
 
-const Variant& pickVariant(const racc_hip_ctx* ctx) {
+// kernel_variant 0 (default): the V2 kernel with the smallest LDS-only stack that covers the tree height (measured
+// best: no spill branches on the hot path), falling back to the 16-level + global-spill instantiation for tall trees.
+const Variant& pickVariant(const racc_hip_ctx* ctx, uint32_t treeHeight) {
     const uint32_t v = ctx->opts.kernel_variant;
-    return kVariants[(v >= 1 && v <= uint32_t(kNumVariants)) ? v - 1 : kDefaultVariant - 1];
+    if (v >= 1 && v <= uint32_t(kNumVariants)) return kVariants[v - 1];
+    if (treeHeight <= 26u) return kVariants[22 - 1];
+    if (treeHeight <= 30u) return kVariants[24 - 1];
+    if (treeHeight <= 32u) return kVariants[14 - 1];
+    return kVariants[kSpillFallback - 1];
 }
 
 int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc_hip_scene* scene, const racc_hip_env* env,
                    const void* dRays, void* dResults, uint32_t count) {
     if (!count) return RACC_HIP_OK;
-    const Variant& v = pickVariant(ctx);
-    const uint32_t ldsBytes = uint32_t(v.cacheNodes) * 64u + uint32_t(v.ldsLevels) * uint32_t(v.block) * 4u;
+    const Variant* vp = &pickVariant(ctx, scene->info.inner_height);
+    if (vp->noSpill && scene->info.inner_height > uint32_t(vp->stackLevels())) vp = &kVariants[kSpillFallback - 1];   // tall tree
+    const Variant& v = *vp;
+    const uint32_t ldsBytes = uint32_t(v.cacheNodes) * 64u + uint32_t(v.ldsLevels) * uint32_t(v.block) * 4u + (v.ldsLevels > 32 ? 272u : 0u);
     const uint32_t wavesPerSimd = optOr(ctx->opts.waves_per_simd, 5u);   // measured best on 1M-ray batches (profiles/)
     const uint32_t wavesPerBlock = uint32_t(v.block) / 64u;
     uint32_t blocksPerCU = (wavesPerSimd * 4u) / wavesPerBlock;
@@ -537,7 +1099,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     const uint32_t blocksNeeded = (count + uint32_t(v.block) - 1) / uint32_t(v.block);
     if (blocks > blocksNeeded) blocks = blocksNeeded;
     const uint32_t gridThreads = blocks * uint32_t(v.block);
-    const uint32_t spillLevels = scene->info.inner_height > uint32_t(v.ldsLevels) ? scene->info.inner_height - uint32_t(v.ldsLevels) : 0u;
+    const uint32_t spillLevels = scene->info.inner_height > uint32_t(v.stackLevels()) ? scene->info.inner_height - uint32_t(v.stackLevels()) : 0u;
     if (int rc = ensureSpill(ctx, lane, uint32_t(ctx->numCUs) * 2048u, spillLevels)) return rc;
 
     TraverseArgs a;
@@ -546,6 +1108,8 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.count = count;
     a.nodes = scene->nodes; a.pairs = scene->pairs; a.remap = scene->remap;
     a.cacheCount = scene->info.node_count < uint32_t(v.cacheNodes) ? scene->info.node_count : uint32_t(v.cacheNodes);
+    a.nodeBytes = scene->info.node_count * 64u;
+    a.pairBytes = scene->info.pair_count * 48u;
     a.env = env ? env->pixels : nullptr;
     a.envW = env ? env->width : 0; a.envH = env ? env->height : 0;
     a.cursor = lane.cursor;
@@ -553,15 +1117,29 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.spillStride = gridThreads;
     a.chunk = optOr(ctx->opts.chunk, 64u);
     a.refillMin = optOr(ctx->opts.refill_min, 32u);
-    a.leafMin = optOr(ctx->opts.leaf_min, 8u);
+    a.leafMin = optOr(ctx->opts.leaf_min, 12u);
     a.maxIters = 1u << 24;
+    a.tailActive = ctx->opts.tail_active ? (ctx->opts.tail_active > 64u ? 0u : ctx->opts.tail_active) : 16u;   // >64 disables
+    a.regroup = optOr(ctx->opts.regroup_period, 8u);
     a.stats = reinterpret_cast<unsigned long long*>(lane.cursor + 8);
     hipLaunchKernelGGL(v.kernel, dim3(blocks), dim3(v.block), 0, stream, a);
     HIP_TRY(hipGetLastError(), "launch traverseKernel");
+    lane.pendingEnv = v.deferEnv && env != nullptr;
     lane.info.grid_blocks = blocks;
     lane.info.block_threads = uint32_t(v.block);
     lane.info.lds_bytes_per_block = ldsBytes;
     lane.info.waves_per_simd = blocksPerCU * wavesPerBlock / 4u;
+    return RACC_HIP_OK;
+}
+
+int launchEnvShade(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc_hip_env* env, void* dResults, uint32_t count) {
+    if (!lane.pendingEnv || !env || !count) return RACC_HIP_OK;
+    lane.pendingEnv = false;
+    uint32_t blocks = (count + 255u) / 256u;
+    const uint32_t cap = uint32_t(ctx->numCUs) * 8u;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(envShadeKernel, dim3(blocks), dim3(256), 0, stream, static_cast<float4*>(dResults), count, env->pixels, env->width, env->height);
+    HIP_TRY(hipGetLastError(), "launch envShadeKernel");
     return RACC_HIP_OK;
 }
 
@@ -679,8 +1257,8 @@ int racc_hip_scene_upload(racc_hip_ctx* ctx, const void* nodes64, uint32_t node_
     info.node_count = node_count; info.pair_count = pair_count; info.remap_count = remap_count;
     info.device_bytes = nb + pb + rb;
     {
-        const Variant& v = pickVariant(ctx);
-        info.spill_levels = info.inner_height > uint32_t(v.ldsLevels) ? info.inner_height - uint32_t(v.ldsLevels) : 0u;
+        const Variant& v = pickVariant(ctx, info.inner_height);
+        info.spill_levels = info.inner_height > uint32_t(v.stackLevels()) ? info.inner_height - uint32_t(v.stackLevels()) : 0u;
     }
     s->info = info;
     *out = s;
@@ -770,6 +1348,7 @@ int racc_hip_intersect_async(racc_hip_ctx* ctx, const racc_hip_scene* scene, con
     if (int rc = ensureStaging(l, count)) return rc;
     HIP_TRY(hipMemcpyAsync(l.dRays, rays, size_t(count) * 32, hipMemcpyHostToDevice, l.stream), "H2D rays");
     if (int rc = launchTraverse(ctx, l, l.stream, scene, env, l.dRays, l.dResults, count)) return rc;
+    if (int rc = launchEnvShade(ctx, l, l.stream, env, l.dResults, count)) return rc;
     HIP_TRY(hipMemcpyAsync(results, l.dResults, size_t(count) * 16, hipMemcpyDeviceToHost, l.stream), "D2H results");
     return RACC_HIP_OK;
 }
@@ -812,6 +1391,7 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
         off += counts[i];
     }
     if (int rc = launchTraverse(ctx, l, l.stream, scene, env, l.dRays, l.dResults, uint32_t(total))) return rc;
+    if (int rc = launchEnvShade(ctx, l, l.stream, env, l.dResults, uint32_t(total))) return rc;
     off = 0;
     for (uint32_t i = 0; i < n_streams; ++i) {
         if (!counts[i]) continue;
@@ -830,7 +1410,9 @@ int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, co
     if (!d_rays || !d_results) return fail(RACC_HIP_ERR_INVALID, "d_rays/d_results is NULL");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     Lane& l = ctx->lanes[lane];
-    return launchTraverse(ctx, l, stream ? static_cast<hipStream_t>(stream) : l.stream, scene, env, d_rays, d_results, count);
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : l.stream;
+    if (int rc = launchTraverse(ctx, l, st, scene, env, d_rays, d_results, count)) return rc;
+    return launchEnvShade(ctx, l, st, env, d_results, count);
 }
 
 int racc_hip_intersect_device_timed(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
@@ -849,7 +1431,8 @@ int racc_hip_intersect_device_timed(racc_hip_ctx* ctx, const racc_hip_scene* sce
     for (uint32_t i = 0; i < iters; ++i) {
         HIP_TRY(hipEventRecord(l.events[2 * i], l.stream), "hipEventRecord");
         if (int rc = launchTraverse(ctx, l, l.stream, scene, env, d_rays, d_results, count)) return rc;
-        HIP_TRY(hipEventRecord(l.events[2 * i + 1], l.stream), "hipEventRecord");
+        HIP_TRY(hipEventRecord(l.events[2 * i + 1], l.stream), "hipEventRecord");      // brackets the traversal kernel alone
+        if (int rc = launchEnvShade(ctx, l, l.stream, env, d_results, count)) return rc;
     }
     HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
     for (uint32_t i = 0; i < iters; ++i)
@@ -865,14 +1448,14 @@ int racc_hip_get_launch_info(racc_hip_ctx* ctx, uint32_t lane, racc_hip_launch_i
     return RACC_HIP_OK;
 }
 
-int racc_hip_read_stats(racc_hip_ctx* ctx, uint32_t lane, uint64_t* stats8, int reset) {
+int racc_hip_read_stats(racc_hip_ctx* ctx, uint32_t lane, uint64_t* stats8 /* [16] */, int reset) {
     if (int rc = checkLane(ctx, lane)) return rc;
     if (!stats8) return fail(RACC_HIP_ERR_INVALID, "stats8 is NULL");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     Lane& l = ctx->lanes[lane];
     HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
-    HIP_TRY(hipMemcpy(stats8, l.cursor + 8, 64, hipMemcpyDeviceToHost), "hipMemcpy stats");
-    if (reset) HIP_TRY(hipMemset(l.cursor + 8, 0, 64), "hipMemset stats");
+    HIP_TRY(hipMemcpy(stats8, l.cursor + 8, 128, hipMemcpyDeviceToHost), "hipMemcpy stats");
+    if (reset) HIP_TRY(hipMemset(l.cursor + 8, 0, 128), "hipMemset stats");
     return RACC_HIP_OK;
 }
 

@@ -39,7 +39,7 @@ class RaccError(RuntimeError):
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("lanes", C.c_uint32), ("waves_per_simd", C.c_uint32),
                 ("kernel_variant", C.c_uint32), ("refill_min", C.c_uint32), ("leaf_min", C.c_uint32),
-                ("chunk", C.c_uint32), ("reserved", C.c_uint32 * 9)]
+                ("chunk", C.c_uint32), ("tail_active", C.c_uint32), ("regroup_period", C.c_uint32), ("reserved", C.c_uint32 * 7)]
 
 
 class SceneInfo(C.Structure):
@@ -233,11 +233,12 @@ class DeviceBuffer:
 class Context:
     """≙ racc::Context for the GPU intersect path; one per (process, GPU)."""
 
-    def __init__(self, device=0, lanes=0, waves_per_simd=0, refill_min=0, leaf_min=0, chunk=0, kernel_variant=0):
+    def __init__(self, device=0, lanes=0, waves_per_simd=0, refill_min=0, leaf_min=0, chunk=0, kernel_variant=0, tail_active=0, regroup_period=0):
         lib = load_library()
         o = Options()
         o.struct_size = C.sizeof(Options)
         o.lanes, o.waves_per_simd, o.refill_min, o.leaf_min, o.chunk, o.kernel_variant = lanes, waves_per_simd, refill_min, leaf_min, chunk, kernel_variant
+        o.tail_active, o.regroup_period = tail_active, regroup_period
         h = C.c_void_p()
         _check(lib.racc_hip_create(device, C.byref(o), C.byref(h)))
         self._h = h
@@ -318,9 +319,10 @@ class Context:
         return {f: getattr(info, f) for f, _ in LaunchInfo._fields_}
 
     def read_stats(self, lane=0, reset=True):
-        st = (C.c_uint64 * 8)()
+        st = (C.c_uint64 * 16)()
         _check(load_library().racc_hip_read_stats(self._h, lane, st, 1 if reset else 0))
-        keys = ("inner_iters", "inner_lanes", "leaf_iters", "leaf_lanes", "refill_iters", "rays_loaded", "dequeues", "waves")
+        keys = ("inner_iters", "inner_lanes", "leaf_iters", "leaf_lanes", "refill_iters", "rays_loaded", "dequeues", "waves",
+                "cy_inner", "cy_inner_load", "cy_leaf", "cy_leaf_load", "cy_refill", "cy_wave", "cy_shuffle", "shuffles")
         return dict(zip(keys, [int(x) for x in st]))
 
     def alloc(self, nbytes):

@@ -27,13 +27,13 @@ def main():
     B1, B2 = orc.algorithmic_bytes(ref, nv, npp), orc.algorithmic_bytes(ref2, nv2, np2)
     print("alg bytes/ray primary %.0f diffuse %.0f; nv %.1f/%.1f np %.2f/%.2f depth %d/%d" % (B1 / len(rays), B2 / len(bounce), nv.mean(), nv2.mean(), npp.mean(), np2.mean(), dp.max(), dp2.max()), flush=True)
     combos = [dict()]
-    for v in range(1, 10):
+    for v in (1, 10, 11, 13):
         combos.append(dict(kernel_variant=v))
-    for v in (1, 2, 6):
-        for w in (4, 5, 6):
+    for v in (1, 10, 11):
+        for w in (4, 5, 6, 8):
             combos.append(dict(kernel_variant=v, waves_per_simd=w))
-    for lf, rf in ((4, 32), (8, 24), (8, 40), (12, 32), (16, 32), (8, 16), (8, 8)):
-        combos.append(dict(kernel_variant=9, leaf_min=lf, refill_min=rf, waves_per_simd=5))
+    for lf, rf in ((4, 32), (8, 24), (8, 40), (8, 48), (12, 32), (16, 32), (6, 32)):
+        combos.append(dict(kernel_variant=10, leaf_min=lf, refill_min=rf))
     first = True
     for opt in combos:
         with ra.Context(device=0, **opt) as ctx:
@@ -52,7 +52,7 @@ def main():
                 m = float(np.median(ms))
                 out[name] = dict(ms=round(m, 4), mrays=round(len(batch) / m / 1e3, 1), gbs=round(B / m / 1e6, 1))
                 d_r.free(); d_o.free()
-            if opt.get("kernel_variant") == 9:
+            if opt.get("kernel_variant") in (9, 12):
                 ctx.read_stats()
                 d_r = ctx.alloc(bounce.nbytes); d_o = ctx.alloc(len(bounce) * 16); d_r.upload(bounce)
                 ctx.intersect_device_timed(scene, env, d_r.ptr, d_o.ptr, len(bounce), 1)

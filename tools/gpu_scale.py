@@ -12,7 +12,9 @@ rays, _ = synth.primary_rays(sc["camera"], 1024, 1024)
 ref = orc.traverse(host.blobs(), rays, threads=16)
 batches = [synth.diffuse_bounce_rays(sc, rays, ref, 1 << 20, first_sample=s) for s in range(8)]
 big = np.concatenate(batches)
-for opt in (dict(kernel_variant=1, waves_per_simd=5), dict(kernel_variant=1, waves_per_simd=8), dict(kernel_variant=1, waves_per_simd=4), dict(kernel_variant=2)):
+import json as _j
+opts = [_j.loads(a) for a in sys.argv[1:]] or [dict(kernel_variant=1), dict(kernel_variant=10), dict(kernel_variant=10, tail_active=100), dict(kernel_variant=10, tail_active=32), dict(kernel_variant=10, tail_active=8), dict(kernel_variant=11)]
+for opt in opts:
     with ra.Context(device=0, **opt) as ctx:
         scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
         env = ctx.create_environment(sc["env"])

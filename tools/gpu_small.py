@@ -26,4 +26,8 @@ for opt in (dict(kernel_variant=9, waves_per_simd=5),):
             st = ctx.read_stats()
             w = st["waves"] / 5
             print(json.dumps(dict(n=n, ms=round(float(np.median(ms)), 4), waves=w, inner_per_wave=round(st["inner_iters"] / 5 / w, 1), leaf_per_wave=round(st["leaf_iters"] / 5 / w, 1),
-                                  refill_per_wave=round(st["refill_iters"] / 5 / w, 1), inner_util=round(st["inner_lanes"] / max(1, st["inner_iters"]) / 64, 3))), flush=True)
+                                  refill_per_wave=round(st["refill_iters"] / 5 / w, 1), inner_util=round(st["inner_lanes"] / max(1, st["inner_iters"]) / 64, 3),
+                                  cyc_per_inner=round(st["cy_inner"] / max(1, st["inner_iters"])), cyc_inner_load=round(st["cy_inner_load"] / max(1, st["inner_iters"])),
+                                  cyc_per_leaf=round(st["cy_leaf"] / max(1, st["leaf_iters"])), cyc_leaf_load=round(st["cy_leaf_load"] / max(1, st["leaf_iters"])),
+                                  cyc_per_refill=round(st["cy_refill"] / max(1, st["refill_iters"])), wave_life_cyc=round(st["cy_wave"] / 5 / w),
+                                  frac_inner=round(st["cy_inner"] / st["cy_wave"], 3), frac_leaf=round(st["cy_leaf"] / st["cy_wave"], 3), frac_refill=round(st["cy_refill"] / st["cy_wave"], 3))), flush=True)
