@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (profiling runs)")
     ap.add_argument("--grid", type=int, default=700, help="height-field resolution of battlefield-synth (700 = full)")
     args = ap.parse_args()
 
@@ -121,7 +122,7 @@ def main():
         torch.cuda.synchronize()
         extras["allgather_results_ms"] = round((time.perf_counter() - t1) / 5 * 1e3, 4)
         extras["allgather_bytes"] = int(gathered.numel() * 4)
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         d_prim = torch.from_numpy(primary.view(np.float32).reshape(len(primary), 8).copy()).cuda()
         d_prim_out = torch.zeros((len(primary), 4), dtype=torch.float32, device="cuda")
         run(2, d_prim, d_prim_out)
@@ -148,17 +149,22 @@ def main():
             got = d_out.cpu().numpy().view(ra.RESULT_DTYPE).reshape(-1)
             if not np.array_equal(got["triangle"], ref["triangle"]):
                 sys.exit("bench: GPU results differ from the oracle — refusing to report a number")
-            threads = os.cpu_count() or 1
+            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cpu_out = np.zeros(n, oracle.RESULT_DTYPE)
+            oracle.traverse(blobs, bounce, env=sc["env"], threads=threads, out=cpu_out)          # warm-up: faults pages, starts clocks
+            t1 = time.perf_counter()
+            oracle.traverse(blobs, bounce, env=sc["env"], threads=threads, out=cpu_out)
+            one = time.perf_counter() - t1
+            repeat = int(min(64, max(2, 12.0 / max(one, 1e-3))))                                 # ~10-15 s of CPU work in total
             times = []
-            oracle.traverse(blobs, bounce, env=sc["env"], threads=threads)
-            for _ in range(5):
+            for _ in range(3):
                 t1 = time.perf_counter()
-                oracle.traverse(blobs, bounce, env=sc["env"], threads=threads)
-                times.append(time.perf_counter() - t1)
+                oracle.traverse(blobs, bounce, env=sc["env"], threads=threads, repeat=repeat, out=cpu_out)
+                times.append((time.perf_counter() - t1) / repeat)
             cpu_baseline = {"value": round(n / float(np.median(times)) / 1e6, 2), "unit": "Mrays/s", "cores": threads,
                             "kind": "port",
-                            "sample": "the full 1,048,576-ray diffuse batch, median of 5 passes, %d pthreads x 1024-ray slices; "
-                                      "CPU BVH2 restatement standing in for Embree (Embree unavailable)" % threads}
+                            "sample": "the full 1,048,576-ray diffuse batch, %d passes per timing x 3 timings (median), %d pthreads x "
+                                      "1024-ray slices; CPU BVH2 restatement standing in for Embree (Embree unavailable)" % (repeat, threads)}
         else:
             try:
                 with open(os.path.join(ROOT, "tests", "golden", "algorithmic_bytes.json")) as f:

@@ -48,7 +48,7 @@ def lib():
         _lib.orc_scene_pack.restype = C.c_int
         _lib.orc_traverse.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, u32, u32, vp, vp, vp]
         _lib.orc_traverse.restype = None
-        _lib.orc_traverse_mt.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, u32, u32, u32]
+        _lib.orc_traverse_mt.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, u32, u32, u32, u32]
         _lib.orc_traverse_mt.restype = None
         _lib.orc_env_sample.argtypes = [vp, u32, u32, vp, vp]
         _lib.orc_env_sample.restype = None
@@ -110,13 +110,14 @@ def build_scene(vertices, indices):
     return scene_pack(nodes, tris, vertices, indices)
 
 
-def traverse(scene, rays, env=None, counters=False, threads=1):
+def traverse(scene, rays, env=None, counters=False, threads=1, repeat=1, out=None):
     """Kernels.h `traversal` restatement.  rays: RAY_DTYPE[N] -> RESULT_DTYPE[N]
     (+ nv, np, depth uint32[N] when counters)."""
     rays = np.ascontiguousarray(rays)
     assert rays.dtype == RAY_DTYPE
     n = len(rays)
-    out = np.zeros(n, RESULT_DTYPE)
+    if out is None:
+        out = np.zeros(n, RESULT_DTYPE)
     envp, w, h = None, 0, 0
     if env is not None:
         env = np.ascontiguousarray(env, dtype=np.float32)
@@ -127,8 +128,8 @@ def traverse(scene, rays, env=None, counters=False, threads=1):
         nv, npp, dp = (np.zeros(n, np.uint32) for _ in range(3))
         lib().orc_traverse(_p(nodes), _p(pairs), _p(remap), envp, w, h, _p(rays), _p(out), 0, n, _p(nv), _p(npp), _p(dp))
         return out, nv, npp, dp
-    if threads > 1:
-        lib().orc_traverse_mt(_p(nodes), _p(pairs), _p(remap), envp, w, h, _p(rays), _p(out), n, 1024, threads)
+    if threads > 1 or repeat > 1:
+        lib().orc_traverse_mt(_p(nodes), _p(pairs), _p(remap), envp, w, h, _p(rays), _p(out), n, 1024, threads, repeat)
     else:
         lib().orc_traverse(_p(nodes), _p(pairs), _p(remap), envp, w, h, _p(rays), _p(out), 0, n, None, None, None)
     return out

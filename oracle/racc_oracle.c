@@ -263,14 +263,17 @@ typedef struct {
     const orc_gpu_node* nodes; const orc_pair* pairs; const uint32_t* remap;
     const float* env; uint32_t envW, envH;
     const orc_ray* rays; orc_result* results; uint32_t count, slice;
-    uint32_t* cursor;
+    uint64_t* cursor;      /* counts slices over `repeat` passes of the batch */
+    uint32_t repeat;
 } mt_job;
 
 static void* mt_worker(void* arg) {
     mt_job* j = (mt_job*)arg;
+    const uint64_t perPass = ((uint64_t)j->count + j->slice - 1) / j->slice;
     for (;;) {
-        const uint32_t s = __atomic_fetch_add(j->cursor, j->slice, __ATOMIC_RELAXED);
-        if (s >= j->count) break;
+        const uint64_t k = __atomic_fetch_add(j->cursor, 1, __ATOMIC_RELAXED);
+        if (k >= perPass * j->repeat) break;
+        const uint32_t s = (uint32_t)((k % perPass) * j->slice);
         const uint32_t e = s + j->slice < j->count ? s + j->slice : j->count;
         orc_traverse(j->nodes, j->pairs, j->remap, j->env, j->envW, j->envH, j->rays, j->results, s, e, 0, 0, 0);
     }
@@ -280,11 +283,12 @@ static void* mt_worker(void* arg) {
 void orc_traverse_mt(const orc_gpu_node* nodes, const orc_pair* pairs, const uint32_t* remap,
                      const float* env, uint32_t envW, uint32_t envH,
                      const orc_ray* rays, orc_result* results, uint32_t count,
-                     uint32_t slice, uint32_t threads) {
+                     uint32_t slice, uint32_t threads, uint32_t repeat) {
     if (!slice) slice = 1024;
     if (!threads) threads = 1;
-    uint32_t cursor = 0;
-    mt_job job = { nodes, pairs, remap, env, envW, envH, rays, results, count, slice, &cursor };
+    if (!repeat) repeat = 1;
+    uint64_t cursor = 0;
+    mt_job job = { nodes, pairs, remap, env, envW, envH, rays, results, count, slice, &cursor, repeat };
     pthread_t* tid = (pthread_t*)malloc(sizeof(pthread_t) * threads);
     for (uint32_t t = 1; t < threads; ++t) pthread_create(&tid[t], 0, mt_worker, &job);
     mt_worker(&job);

@@ -76,12 +76,13 @@ void orc_traverse(const orc_gpu_node* nodes, const orc_pair* pairs, const uint32
 void orc_set_visit_histogram(uint32_t* hist);
 
 /* Same as orc_traverse over [0,count) in slices of `slice` rays
- * (cpuTestBatch = 1024, RayAccelerator.cpp:197-212,438) on `threads` pthreads.
- * Used by bench.py's cpu_baseline leg ("port"). */
+ * (cpuTestBatch = 1024, RayAccelerator.cpp:197-212,438) on `threads` pthreads,
+ * `repeat` passes over the batch inside one call (so that thread start-up is
+ * amortised when timing).  Used by bench.py's cpu_baseline leg ("port"). */
 void orc_traverse_mt(const orc_gpu_node* nodes, const orc_pair* pairs, const uint32_t* remap,
                      const float* env, uint32_t envW, uint32_t envH,
                      const orc_ray* rays, orc_result* results, uint32_t count,
-                     uint32_t slice, uint32_t threads);
+                     uint32_t slice, uint32_t threads, uint32_t repeat);
 
 /* Kernels.h:213-222 — miss colour for a (clamped) direction; OpenCL
  * CLK_NORMALIZED_COORDS_TRUE | CLAMP_TO_EDGE | FILTER_LINEAR semantics. */
