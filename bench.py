@@ -35,6 +35,25 @@ def _committed_traffic():
         return None
 
 
+def usable_cores():
+    """Host cores this process may really use: CPU affinity capped by the cgroup CPU quota (the GPU boxes expose 256
+    logical CPUs but grant 16 CPUs of quota; more threads than that only oversubscribes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,10 +81,17 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # RACC_BENCH_BACKEND=gloo + RACC_BENCH_DEVICE=0 let the N>1 flow be rehearsed on a 1-GPU box (ranks share GPU 0);
+    # the real thing is nccl (= RCCL over xGMI), one rank per GPU.
+    backend = os.environ.get("RACC_BENCH_BACKEND", "nccl")
+    device = int(os.environ.get("RACC_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -75,7 +101,7 @@ def main():
     full = args.grid == 700
     sc = synth.battlefield_synth() if full else synth.battlefield_synth(grid=args.grid, boxes=args.grid * 6, quads=args.grid * 28)
     host = ra.HostScene(sc["vertices"], sc["indices"])
-    ctx = ra.Context(device=local_rank)
+    ctx = ra.Context(device=device)
     scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
     env = ctx.create_environment(sc["env"])
 
@@ -103,7 +129,7 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -112,7 +138,7 @@ def main():
 
     # ---- optional extras, all outside the timed region ------------------------------------------
     extras = {}
-    if world > 1:   # RCCL all-gather of the Result shards over xGMI (only needed by a GPU-side consumer)
+    if world > 1 and backend == "nccl":   # RCCL all-gather of the Result shards over xGMI (only needed by a GPU-side consumer)
         gathered = torch.empty((world * n, 4), dtype=torch.float32, device="cuda")
         dist.all_gather_into_tensor(gathered, d_out)
         torch.cuda.synchronize(); barrier()
@@ -128,6 +154,24 @@ def main():
         run(2, d_prim, d_prim_out)
         pm = float(np.median(run(10, d_prim, d_prim_out)))
         extras["coherent_1M"] = {"ms_per_step": round(pm, 4), "mrays_per_s": round(len(primary) / pm / 1e3, 1)}
+        # The reference keeps gpuSubmissionThreads (4) streams in flight (RayAccelerator.cpp:436,711-717).  Same K steps
+        # issued round-robin over 4 lanes (HIP streams): launches overlap, so one launch's drain hides under the next
+        # one's bulk.  Reported beside `value`, which stays the one-launch-at-a-time figure the roofline is quoted on.
+        outs = [torch.zeros((n, 4), dtype=torch.float32, device="cuda") for _ in range(4)]
+        for lane in range(4):
+            ctx.intersect_device(scene, env, d_rays.data_ptr(), outs[lane].data_ptr(), n, lane=lane)
+        for lane in range(4):
+            ctx.wait(lane)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            ctx.intersect_device(scene, env, d_rays.data_ptr(), outs[k % 4].data_ptr(), n, lane=k % 4)
+        for lane in range(4):
+            ctx.wait(lane)
+        torch.cuda.synchronize()
+        extras["four_streams_in_flight_mrays_per_s"] = round(args.steps * n / (time.perf_counter() - t1) / 1e6, 1)
+        if not torch.equal(outs[0].view(torch.int32), d_out.view(torch.int32)):   # bit compare (a miss id reads as NaN in f32)
+            sys.exit("bench: overlapped launches changed the results")
         # PCIe-inclusive rate of the host-buffer entry point (never `value`)
         res_host = np.zeros(n, ra.RESULT_DTYPE)
         ctx.intersect(scene, env, bounce, res_host)
@@ -149,7 +193,7 @@ def main():
             got = d_out.cpu().numpy().view(ra.RESULT_DTYPE).reshape(-1)
             if not np.array_equal(got["triangle"], ref["triangle"]):
                 sys.exit("bench: GPU results differ from the oracle — refusing to report a number")
-            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            threads = usable_cores()
             cpu_out = np.zeros(n, oracle.RESULT_DTYPE)
             oracle.traverse(blobs, bounce, env=sc["env"], threads=threads, out=cpu_out)          # warm-up: faults pages, starts clocks
             t1 = time.perf_counter()
