@@ -236,3 +236,50 @@ def test_full_size_4M_batch(gpu_ctx, full):
     for k in range(4):
         part = gpu_ctx.intersect(full["scene"], full["env"], rays[k * q:(k + 1) * q])
         assert np.array_equal(part.view(np.uint8), big[k * q:(k + 1) * q].view(np.uint8))
+
+
+def test_many_streams_in_one_launch(gpu_ctx, small):
+    """≙ what racc::render hands a GPU thread: several ray streams, one launch, results in place per stream."""
+    b = _batches(small)
+    streams = [b["primary"][:5000], b["diffuse"][:1], b["random"][:0], b["diffuse"][1:20000], b["random"][:777]]
+    outs = gpu_ctx.intersect_streams(small["scene"], small["env"], streams, lane=1)
+    for rays, got in zip(streams, outs):
+        assert len(got) == len(rays)
+        if len(rays):
+            assert_bit_exact(got, orc.traverse(small["blobs"], rays, env=small["sc"]["env"]), "stream of %d" % len(rays))
+
+
+def test_scheduling_statistics_variant(small_scene, small_host, small):
+    """The debug instantiations count what the scheduler did; every ray must be loaded exactly once and every node
+    visit / pair test of the oracle's count must appear as a live lane in some step."""
+    rays = _batches(small)["diffuse"]
+    ref, nv, npairs, _ = orc.traverse(small["blobs"], rays, counters=True)
+    for variant in (9, 12, 21):
+        with ra.Context(device=0, kernel_variant=variant) as ctx:
+            scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
+            ctx.read_stats()
+            assert_bit_exact(ctx.intersect(scene, None, rays), ref, "stats variant %d" % variant)
+            st = ctx.read_stats()
+            assert st["rays_loaded"] == len(rays)
+            # Same traversal as the reference: V1 counts every live lane of every step exactly.  V2/V3 count at the vote,
+            # and a thin wave's second body also serves lanes that changed kind in the first one, so they under-count.
+            if variant == 9:
+                assert st["inner_lanes"] == int(nv.sum()) and st["leaf_lanes"] == int(npairs.sum())
+            else:
+                assert 0.9 * int(nv.sum()) <= st["inner_lanes"] <= int(nv.sum()) and st["leaf_lanes"] == int(npairs.sum())
+            assert st["inner_iters"] * 64 >= st["inner_lanes"] and st["waves"] > 0
+            scene.destroy()
+
+
+def test_pinned_host_block(gpu_ctx, small):
+    lib = ra.load_library()
+    import ctypes as C
+    rays = small["primary"][:4096].copy()
+    buf = np.zeros(4096 * 48 + 8192, np.uint8)
+    base = (buf.ctypes.data + 4095) & ~4095
+    assert lib.racc_hip_register_host(gpu_ctx._h, C.c_void_p(base), 4096 * 48) == 0
+    C.memmove(base, rays.ctypes.data, rays.nbytes)
+    assert lib.racc_hip_intersect(gpu_ctx._h, small["scene"]._h, small["env"]._h, C.c_void_p(base), C.c_void_p(base + 4096 * 32), 4096, 0) == 0
+    got = np.frombuffer((C.c_char * (4096 * 16)).from_address(base + 4096 * 32), ra.RESULT_DTYPE).copy()
+    assert lib.racc_hip_unregister_host(gpu_ctx._h, C.c_void_p(base)) == 0
+    assert_bit_exact(got, orc.traverse(small["blobs"], rays, env=small["sc"]["env"]), "pinned block")
