@@ -21,6 +21,7 @@ from .synth import RAY_DTYPE, RESULT_DTYPE, INVALID_TRIANGLE  # noqa: F401  (re-
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libracc_hip.so")
 API_LIB_PATH = os.path.join(_HERE, "librayaccelerator.so")       # racc:: C++ interface over the C-ABI
+PT_LIB_PATH = os.path.join(_HERE, "libracc_pathtracer.so")       # path-tracing consumer (BASELINE configs[4])
 CSRC = os.path.join(_HERE, "csrc")
 
 BVH2_NODE_DTYPE = np.dtype([("kind", "<u4"), ("parent", "<u4"), ("first", "<u4"), ("last", "<u4"),
@@ -95,10 +96,10 @@ _lib = None
 
 def build_library(force=False):
     """Compile libracc_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("racc_hip.hip", "scene_build.cpp", "racc_api.cpp", "Makefile")]
+    srcs = [os.path.join(CSRC, f) for f in ("racc_hip.hip", "scene_build.cpp", "racc_api.cpp", "pathtracer.cpp", "Makefile")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("racc_hip.h", "RayAccelerator.h")]
     srcs.append(os.path.join(_HERE, "..", "tests", "cpp", "render_check.cpp"))
-    outs = [LIB_PATH, API_LIB_PATH, os.path.join(_HERE, "..", "tests", "cpp", "render_check")]
+    outs = [LIB_PATH, API_LIB_PATH, PT_LIB_PATH, os.path.join(_HERE, "..", "tests", "cpp", "render_check")]
     stale = any(not os.path.exists(o) for o in outs) or any(os.path.getmtime(s) > min(os.path.getmtime(o) for o in outs) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", CSRC])
@@ -327,3 +328,25 @@ class Context:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+
+class PathTraceStats(C.Structure):
+    _fields_ = [("rays_traced", C.c_uint64), ("primary_rays", C.c_uint64), ("seconds", C.c_double),
+                ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32), ("max_depth", C.c_uint32), ("threads", C.c_uint32),
+                ("triangles", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+def path_trace(scene_bin, width, height, spp_first, spp_count, device=0, max_depth=0, cpu_threads=0):
+    """Render samples [spp_first, spp_first+spp_count) of a reference-format scene file with the path-tracing consumer
+    (rayaccel_amd/csrc/pathtracer.cpp).  Returns (sum of radiance [H,W,3] float64, stats dict)."""
+    load_library()
+    lib = C.CDLL(PT_LIB_PATH)
+    lib.racc_pt_render_file.restype = C.c_int
+    lib.racc_pt_render_file.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.c_void_p, C.POINTER(PathTraceStats)]
+    img = np.zeros((height, width, 3), np.float64)
+    st = PathTraceStats()
+    rc = lib.racc_pt_render_file(os.fsencode(scene_bin), device, width, height, spp_first, spp_count, max_depth, cpu_threads, _ptr(img), C.byref(st))
+    if rc != 0:
+        raise RaccError(rc, "racc_pt_render_file failed")
+    return img, {f: getattr(st, f) for f, _ in PathTraceStats._fields_}
