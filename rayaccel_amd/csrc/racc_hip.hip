@@ -1,25 +1,28 @@
 // racc_hip.hip — gfx950 (MI355X) wavefront BVH2 traversal + the C-ABI around it.
 //
-// Replaces the reference's OpenCL `traversal` kernel (RayAccelerator/Kernels.h:139-242) and its
-// launch path (RayAccelerator/RayAccelerator.cpp:378-404).  Not a translation: the reference runs one
-// work-item per ray in work-groups of 8 with a private int[64] stack and one blocking launch per
-// <=27k-ray stream.  Here:
-//   * persistent waves (wave64) pull rays from a global cursor in chunks and keep their lanes full:
-//     finished lanes are detected with a wave ballot, ranked with mbcnt (prefix sum over the ballot)
-//     and re-loaded with the next rays of the wave's chunk — active-ray compaction at wavefront width;
-//   * each iteration the wave VOTES on what to run: an inner-node step for every lane that holds an
-//     inner node, or a triangle-pair step for every lane that holds a leaf, so neither body is executed
-//     for a handful of lanes ("vote-scheduled while-while"); Moller-Trumbore (the reference's Embree
-//     style pair test, Kernels.h:36-115) is fused into that leaf step;
-//   * the per-ray traversal stack lives in LDS as [level][thread] (bank = thread % 32 at every level, so
-//     pushes/pops never conflict) with a global-memory spill above LDS_LEVELS that is sized from the
-//     real tree height at upload time — unlike the reference's unchecked stack[64] it cannot overflow;
-//   * hit/miss epilogues (remap gather + barycentric rotation, probe-image bilinear) are deferred and
-//     batched into the refill step.
-// Arithmetic is IEEE binary32 with explicit fmaf only (built with -ffp-contract=off, no fast-math), the
-// same evaluation order as oracle/racc_oracle.c, so primId/t/u/v are bit-identical to the CPU
-// restatement for every finite ray.  The traversal ORDER is the reference's (nearer child first, far
-// child pushed only if both hit, pairs of a leaf in order), which is what makes ties resolve identically.
+// Replaces the reference's OpenCL `traversal` kernel (RayAccelerator/Kernels.h:139-242) and its launch path
+// (RayAccelerator/RayAccelerator.cpp:378-404).  Not a translation: the reference runs one work-item per ray in
+// work-groups of 8 with a private int[64] stack and one blocking launch per <=27k-ray stream.  Here:
+//   * persistent waves (wave64) pull rays from a global cursor in chunks and keep their lanes full: finished lanes are
+//     detected with a wave ballot, ranked with mbcnt (prefix sum over the ballot) and re-loaded with the next rays of
+//     the wave's chunk — active-ray compaction at wavefront width;
+//   * each iteration the wave VOTES on what to run: an inner-node step for every lane that holds an inner node, or a
+//     triangle-pair step for every lane that holds a leaf ("vote-scheduled while-while"); Moller-Trumbore (the
+//     reference's Embree-style pair test, Kernels.h:36-115) is fused into that leaf step;
+//   * the per-ray traversal stack lives in LDS as [level][thread] (bank = thread % 32 at every level, so pushes/pops never
+//     conflict), sized from the real tree height at upload time, with a global-memory spill instantiation for tall trees
+//     — unlike the reference's unchecked stack[64] it cannot overflow;
+//   * hit epilogues (remap gather + barycentric rotation) are batched into the refill step; miss radiance is evaluated by
+//     a second, streaming kernel (envShadeKernel).
+// Three generations live in this file and are selectable through racc_hip_options::kernel_variant:
+//   traverseKernel    V1, the first correct kernel, also with an optional LDS cache of the top of the tree;
+//   traverseKernelV2  the shipped one: V1 + thin-wave (drain) policy, lazy epilogues, deferred miss shading;
+//   traverseKernelV3  experiment: workgroup-wide regrouping of rays by phase through LDS (higher lane utilisation,
+//                     lost to its barriers).
+// Arithmetic is IEEE binary32 with explicit fmaf only (built with -ffp-contract=off, no fast-math), the same evaluation
+// order as oracle/racc_oracle.c, so primId/t/u/v are bit-identical to the CPU restatement for every finite ray.  The
+// traversal ORDER is the reference's (nearer child first, far child pushed only if both hit, pairs of a leaf in order),
+// which is what makes ties resolve identically.
 
 #include <hip/hip_runtime.h>
 
@@ -45,10 +48,10 @@ struct TraverseArgs {
     const float4* rays;
     float4* results;
     uint32_t count;
-    const float4* nodes;      // 4 x float4 per inner node (Scene.cpp:73-78 order); the first
-                              // `cacheCount` are the largest-area top of the tree (see reorderNodes)
+    const float4* nodes;      // 64 B device records (see slabPair); the first kCacheMax are the largest-area
+                              // top of the tree (see reorderNodes)
     uint32_t cacheCount;      // nodes [0, cacheCount) are also resident in LDS
-    uint32_t nodeBytes, pairBytes;   // extents for the buffer descriptors of the V2 kernel
+    uint32_t nodeBytes, pairBytes;   // extents for the buffer descriptors (V2 BUF ablation)
     const float4* pairs;      // 3 x float4 per pair (Scene.cpp:83-87 order)
     const uint32_t* remap;
     const float4* env;        // RGBA32F probe image or nullptr
