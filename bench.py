@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_MEASURED_GBS = 6290.0      # same guide: float4-copy ceiling
 RAYS_PER_BATCH = 1 << 20
-KERNEL_NAME = "traverseKernel"
+KERNEL_NAME = "traverseKernelV2"
 
 
 def _committed_traffic():
