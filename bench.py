@@ -209,6 +209,20 @@ def main():
                             "kind": "port",
                             "sample": "the full 1,048,576-ray diffuse batch, %d passes per timing x 3 timings (median), %d pthreads x "
                                       "1024-ray slices; CPU BVH2 restatement standing in for Embree (Embree unavailable)" % (repeat, threads)}
+            # The reference's OWN traversal kernel (oracle/_ref, built from RayAccelerator/Kernels.h with its own flags) on this
+            # same GPU and batch, launched as the reference launches it (work-groups of 8, enqueue + clFinish).
+            try:
+                from oracle import ref_kernel
+                if ref_kernel.built():
+                    ref_res, ref_t = ref_kernel.run(blobs, bounce, sc["env"], repeats=5)
+                    hit = ref["triangle"] != 0xFFFFFFFF
+                    agree = float((ref_res["triangle"][hit] == ref["triangle"][hit]).mean())
+                    extras["reference_opencl_kernel_on_this_gpu"] = {
+                        "mrays_per_s": round(n / float(np.median(ref_t)) / 1e6, 1), "ms_per_launch": round(float(np.median(ref_t)) * 1e3, 3),
+                        "primId_agreement_with_engine": round(agree, 6),
+                        "what": "Kernels.h `traversal`, -cl-fast-relaxed-math, local size 8, same 1M-ray diffuse batch, enqueue + clFinish"}
+            except Exception as e:   # noqa: BLE001 - a missing OpenCL runtime must not fail the bench
+                extras["reference_opencl_kernel_on_this_gpu"] = {"error": str(e)[:200]}
         else:
             try:
                 with open(os.path.join(ROOT, "tests", "golden", "algorithmic_bytes.json")) as f:

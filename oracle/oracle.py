@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg — never by anything under rayaccel_amd/.
-PARITY UNPINNED: see racc_oracle.h.
+Pinned against the reference's own traversal kernel (oracle/_ref, oracle/ref_kernel.py); see racc_oracle.h.
 """
 import ctypes as C
 import os
@@ -29,6 +29,8 @@ def build(force=False):
     src = os.path.join(_HERE, "racc_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libracc_oracle.so"])
+    # oracle/_ref: the reference's own traversal kernel, built only where /root/reference exists (this container)
+    subprocess.call(["make", "-s", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 

@@ -2,7 +2,8 @@
  * racc_oracle.c — CPU restatement of the reference hot path (see racc_oracle.h).
  *
  * TEST INFRASTRUCTURE ONLY — never linked into or loaded by the product.
- * PARITY UNPINNED (no reference tests / golden vectors exist; Embree absent).
+ * Pinned against the reference's own OpenCL kernel run on the MI355X (oracle/_ref,
+ * tests/test_gpu_reference_kernel.py); the Embree CPU path is unavailable.  See racc_oracle.h.
  *
  * Arithmetic contract.  The reference builds its OpenCL kernel with
  * -cl-fast-relaxed-math -cl-mad-enable (RayAccelerator.cpp:489-490), so the

@@ -5,15 +5,21 @@
  * include, link or load this; only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg use it, and only as the checker.
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
- * for this path, its CPU path is three lines of glue around a binary-only
- * third-party library (Intel Embree 2.x, ~2.7.0, absent here), and its own
- * sources cannot be compiled in this image without writing stand-ins for
- * headers/libraries the image lacks (<OpenCL/cl.h> on the Apple branch,
- * <libkern/OSAtomic.h>, libembree).  The restatement below follows the
- * reference's OpenCL traversal kernel and scene flattener line by line and is
+ * PINNING.  The reference ships no tests, golden vectors or fixtures for this
+ * path, and the correctness reference north_star names — its CPU path, three
+ * lines of glue around a binary-only third-party library (Intel Embree 2.x,
+ * ~2.7.0) — cannot run anywhere here (binaries absent, sources not vendored).
+ * What IS available is the reference's own GPU path: oracle/_ref holds its
+ * OpenCL `traversal` kernel, compiled from the source where it lies with the
+ * reference's own build options (oracle/Makefile, target `ref`), and
+ * tests/test_gpu_reference_kernel.py runs it on the MI355X next to this
+ * restatement on the same buffers (1M-ray batches included): primId identical
+ * up to exact-distance ties, t/u/v within 1e-4 relative (the reference kernel
+ * is fast-math, so not bit-comparable).  The restatement is additionally
  * cross-checked against an independent double-precision brute-force arbiter
- * (orc_brute_*), not against outputs of the reference itself.
+ * (orc_brute_*).  The reference's C++ translation units are not built: they
+ * need headers/libraries this image lacks (<OpenCL/cl.h> Apple path,
+ * <libkern/OSAtomic.h>, libembree) and stand-ins for those are not allowed.
  *
  * All file:line citations are relative to /root/reference/.
  */

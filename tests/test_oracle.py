@@ -1,10 +1,10 @@
 """CPU tests of the oracle itself (oracle/racc_oracle.c).
 
-The reference has NO tests, golden vectors or fixtures for this path and its own
-sources cannot be built here, so the oracle is PARITY-UNPINNED against the reference's outputs.  What pins
-it instead: (1) an independent double-precision brute-force arbiter over all triangles, (2) hand-made
-known-answer cases for every quirk SURVEY.md §8(c) lists, (3) self-generated golden vectors under
-tests/golden/ (regression protection; generator: tools/make_golden.py).
+The reference has NO tests, golden vectors or fixtures for this path.  The oracle is pinned to
+the reference itself on the GPU box (tests/test_gpu_reference_kernel.py runs the reference's own OpenCL kernel from
+oracle/_ref); on CPU-only hosts these tests hold it to: (1) an independent double-precision brute-force arbiter over
+all triangles, (2) hand-made known-answer cases for every quirk SURVEY.md §8(c) lists, (3) self-generated golden
+vectors under tests/golden/ (regression protection; generator: tools/make_golden.py).
 """
 import json
 import os
