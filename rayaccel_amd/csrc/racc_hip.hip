@@ -410,12 +410,13 @@ __global__ void __launch_bounds__(BLOCK) traverseKernel(const TraverseArgs a) {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr uint32_t kEmpty = 0u, kDone = 1u;
+constexpr uint32_t kXcdCursorWord = 40;   // cursor block: words 0-2 control, 8-39 statistics, 40-47 per-XCD ray cursors
 
 __device__ __forceinline__ float4 asFloat4(u32x4 v) {
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int BLOCK, int LDS_LEVELS, bool SPILL, bool STATS, bool BUF = true, bool TOS = true>
+template <int BLOCK, int LDS_LEVELS, bool SPILL, bool STATS, bool BUF = true, bool TOS = true, bool XQ = false>
 __global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) {
     __shared__ uint32_t lds[LDS_LEVELS * BLOCK];
     const uint32_t tid = threadIdx.x;
@@ -434,6 +435,7 @@ __global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) 
     uint32_t sp = 0, top = 0;   // stack height; register copy of entry sp-1
     uint32_t wBeg = 0, wEnd = 0;
     bool exhausted = false;
+    uint32_t xqTried = 0;       // XQ: how many of the 8 per-XCD queues this wave has found empty
     uint32_t stInner = 0, stInnerLanes = 0, stLeaf = 0, stLeafLanes = 0, stRefill = 0, stLoaded = 0, stDeq = 0;
     unsigned long long cyInner = 0, cyLeaf = 0, cyRefill = 0, cyStart = 0;
     if (STATS) cyStart = __builtin_readcyclecounter();
@@ -507,12 +509,33 @@ __global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) 
             if (STATS) ++stRefill;
             if (wBeg == wEnd && !exhausted) {
                 if (STATS) ++stDeq;
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(a.cursor, a.chunk);
-                b = __builtin_amdgcn_readfirstlane(b);
-                wBeg = min(b, a.count);
-                wEnd = min(b + a.chunk, a.count);
-                exhausted = (b >= a.count) || (b + a.chunk < b);
+                if (!XQ) {
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(a.cursor, a.chunk);
+                    b = __builtin_amdgcn_readfirstlane(b);
+                    wBeg = min(b, a.count);
+                    wEnd = min(b + a.chunk, a.count);
+                    exhausted = (b >= a.count) || (b + a.chunk < b);
+                } else {
+                    // XCD-partitioned queue: workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own L2.
+                    // The batch is cut into 8 contiguous eighths with a cursor each; a wave drains its own XCD's eighth first
+                    // (neighbouring rays -> the same subtrees stay in that L2) and then steals from the others.
+                    const uint32_t per = ((a.count + 7u) / 8u + a.chunk - 1u) / a.chunk * a.chunk;
+                    for (;;) {
+                        const uint32_t q = (blockIdx.x + xqTried) & 7u;
+                        uint32_t b = 0;
+                        if (lane == 0) b = atomicAdd(a.cursor + kXcdCursorWord + q, a.chunk);
+                        b = __builtin_amdgcn_readfirstlane(b);
+                        const uint64_t lo = uint64_t(q) * per + b;
+                        const uint64_t hi = min(uint64_t(q + 1u) * per, uint64_t(a.count));
+                        if (b < per && lo < hi) {
+                            wBeg = uint32_t(lo);
+                            wEnd = uint32_t(min(lo + a.chunk, hi));
+                            break;
+                        }
+                        if (++xqTried == 8u) { exhausted = true; break; }
+                    }
+                }
             }
             const uint32_t take = min(need, wEnd - wBeg);
             const uint32_t rank = laneRank(emptyMask);
@@ -620,7 +643,10 @@ __global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) 
     __syncthreads();
     if (tid == 0) {
         const uint32_t prev = atomicInc(a.cursor + 1, gridDim.x - 1);
-        if (prev == gridDim.x - 1) atomicExch(a.cursor, 0u);
+        if (prev == gridDim.x - 1) {
+            atomicExch(a.cursor, 0u);
+            if (XQ) for (uint32_t q = 0; q < 8u; ++q) atomicExch(a.cursor + kXcdCursorWord + q, 0u);
+        }
     }
 }
 
@@ -1070,6 +1096,8 @@ const Variant kVariants[] = {
     {256, 26, 0, traverseKernelV2<256, 26, false, false, false, false>, true, true},       // 22: V2, 26 LDS levels, no spill path (26 KiB: 6 WG/CU)
     {256, 28, 0, traverseKernelV2<256, 28, false, false, false, false>, true, true},       // 23: V2, 28 LDS levels, no spill path (28 KiB: 5 WG/CU)
     {256, 30, 0, traverseKernelV2<256, 30, false, false, false, false>, true, true},       // 24: V2, 30 LDS levels, no spill path
+    {256, 26, 0, traverseKernelV2<256, 26, false, false, false, false, true>, true, true}, // 25: variant 22 + per-XCD ray queues (measured slower: DESIGN.md §3)
+    {256, 26, 0, traverseKernelV2<256, 26, false, true, false, false, false>, true, true}, // 26: variant 22 + statistics (debug)
 };
 constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kSpillFallback = 17;    // V2 with 16 LDS levels + global spill: used when a tree is taller than a variant's LDS stack
