@@ -185,7 +185,7 @@ def main():
     if rank == 0:
         avg_kernel_ms = float(np.mean(kernel_ms))
         alg_bytes, src = None, None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # the CPU legs run at N=1 only
             from oracle import oracle            # checker / CPU leg only; never on the product path
             blobs = host.blobs()
             ref, nv, npairs, _ = oracle.traverse(blobs, bounce, env=sc["env"], counters=True)

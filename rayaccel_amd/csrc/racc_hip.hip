@@ -52,6 +52,8 @@ struct TraverseArgs {
                               // top of the tree (see reorderNodes)
     uint32_t cacheCount;      // nodes [0, cacheCount) are also resident in LDS
     uint32_t nodeBytes, pairBytes;   // extents for the buffer descriptors (V2 BUF ablation)
+    const float4* nodesSoa;   // SOA ablation only: the same records transposed into 4 planes of nodeCount float4 each
+    uint32_t nodeCount;
     const float4* pairs;      // 3 x float4 per pair (Scene.cpp:83-87 order)
     const uint32_t* remap;
     const float4* env;        // RGBA32F probe image or nullptr
@@ -416,7 +418,7 @@ __device__ __forceinline__ float4 asFloat4(u32x4 v) {
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int BLOCK, int LDS_LEVELS, bool SPILL, bool STATS, bool BUF = true, bool TOS = true, bool XQ = false>
+template <int BLOCK, int LDS_LEVELS, bool SPILL, bool STATS, bool BUF = true, bool TOS = true, bool XQ = false, bool SOA = false>
 __global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) {
     __shared__ uint32_t lds[LDS_LEVELS * BLOCK];
     const uint32_t tid = threadIdx.x;
@@ -607,6 +609,14 @@ __global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) 
                     d1 = asFloat4(__builtin_amdgcn_raw_buffer_load_b128(nodeRsrc, off + 16u, 0, 0));
                     d2 = asFloat4(__builtin_amdgcn_raw_buffer_load_b128(nodeRsrc, off + 32u, 0, 0));
                     d3 = asFloat4(__builtin_amdgcn_raw_buffer_load_b128(nodeRsrc, off + 48u, 0, 0));
+                } else if (SOA) {
+                    // Ablation of the "SoA in HBM" layout: plane p of node i lives at nodesSoa[p * nodeCount + i].  Every lane
+                    // is at a different node, so the four 16 B reads of one visit land in four cache lines instead of one.
+                    const float4* np = a.nodesSoa + size_t(node & 0x7FFFFFFFu);
+                    const uint2 k2 = *reinterpret_cast<const uint2*>(np);
+                    d1 = np[size_t(a.nodeCount)]; d2 = np[size_t(a.nodeCount) * 2]; d3 = np[size_t(a.nodeCount) * 3];
+                    asm volatile("" :: "v"(k2.x), "v"(k2.y));
+                    kids.x = k2.x; kids.y = k2.y;
                 } else {
                     const float4* np = a.nodes + size_t(node & 0x7FFFFFFFu) * 4;
                     const uint2 k2 = *reinterpret_cast<const uint2*>(np);
@@ -958,6 +968,7 @@ struct racc_hip_ctx {
 
 struct racc_hip_scene {
     float4* nodes = nullptr;
+    float4* nodesSoa = nullptr;     // only when the context asks for the SoA ablation variant
     float4* pairs = nullptr;
     uint32_t* remap = nullptr;
     racc_hip_scene_info info{};
@@ -1098,8 +1109,10 @@ const Variant kVariants[] = {
     {256, 30, 0, traverseKernelV2<256, 30, false, false, false, false>, true, true},       // 24: V2, 30 LDS levels, no spill path
     {256, 26, 0, traverseKernelV2<256, 26, false, false, false, false, true>, true, true}, // 25: variant 22 + per-XCD ray queues (measured slower: DESIGN.md §3)
     {256, 26, 0, traverseKernelV2<256, 26, false, true, false, false, false>, true, true}, // 26: variant 22 + statistics (debug)
+    {256, 26, 0, traverseKernelV2<256, 26, false, false, false, false, false, true>, true, true}, // 27: variant 22 with the node records transposed to SoA planes (ablation: DESIGN.md §2)
 };
 constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
+constexpr int kSoaVariant = 27;
 constexpr int kSpillFallback = 17;    // V2 with 16 LDS levels + global spill: used when a tree is taller than a variant's LDS stack
 constexpr uint32_t kLdsPerCU = 160u * 1024u;
 
@@ -1140,6 +1153,8 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.nodes = scene->nodes; a.pairs = scene->pairs; a.remap = scene->remap;
     a.cacheCount = scene->info.node_count < uint32_t(v.cacheNodes) ? scene->info.node_count : uint32_t(v.cacheNodes);
     a.nodeBytes = scene->info.node_count * 64u;
+    a.nodesSoa = scene->nodesSoa; a.nodeCount = scene->info.node_count;
+    if (&v == &kVariants[kSoaVariant - 1] && !scene->nodesSoa) return fail(RACC_HIP_ERR_INVALID, "the SoA ablation variant needs a scene uploaded through a context created with that variant");
     a.pairBytes = scene->info.pair_count * 48u;
     a.env = env ? env->pixels : nullptr;
     a.envW = env ? env->width : 0; a.envH = env ? env->height : 0;
@@ -1282,6 +1297,15 @@ int racc_hip_scene_upload(racc_hip_ctx* ctx, const void* nodes64, uint32_t node_
     std::vector<GpuNodeHost> ordered;
     reorderNodes(static_cast<const GpuNodeHost*>(nodes64), node_count, ordered);
     if (e == hipSuccess) e = hipMemcpy(s->nodes, ordered.data(), nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && ctx->opts.kernel_variant == uint32_t(kSoaVariant)) {
+        std::vector<float> planes(size_t(node_count) * 16);
+        const float* rec = reinterpret_cast<const float*>(ordered.data());
+        for (uint32_t i = 0; i < node_count; ++i)
+            for (uint32_t p = 0; p < 4; ++p)
+                std::memcpy(&planes[(size_t(p) * node_count + i) * 4], rec + size_t(i) * 16 + p * 4, 16);
+        e = hipMalloc(reinterpret_cast<void**>(&s->nodesSoa), nb);
+        if (e == hipSuccess) e = hipMemcpy(s->nodesSoa, planes.data(), nb, hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMemcpy(s->pairs, pairs48, pb, hipMemcpyHostToDevice);
     if (e == hipSuccess && rb) e = hipMemcpy(s->remap, remap, rb, hipMemcpyHostToDevice);
     if (e != hipSuccess) { racc_hip_scene_free(ctx, s); return fail(RACC_HIP_ERR_DEVICE, "scene upload", e); }
@@ -1300,6 +1324,7 @@ int racc_hip_scene_free(racc_hip_ctx* ctx, racc_hip_scene* s) {
     if (!s) return RACC_HIP_OK;
     if (ctx) hipSetDevice(ctx->device);
     if (s->nodes) hipFree(s->nodes);
+    if (s->nodesSoa) hipFree(s->nodesSoa);
     if (s->pairs) hipFree(s->pairs);
     if (s->remap) hipFree(s->remap);
     delete s;
