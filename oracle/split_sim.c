@@ -214,6 +214,7 @@ static unsigned long long sim_wave(const orc_ray* rays, uint32_t count, uint32_t
     uint32_t chunk = firstChunk, wBeg = 0, wEnd = 0;
     int exhausted = 0;
     unsigned long long drain = 0;
+    const unsigned long long cost0 = st->drainIters;
     for (int i = 0; i < WAVE; ++i) lanes[i].node = K_EMPTY;
     for (;;) {
         const int draining = exhausted && wBeg == wEnd;
@@ -258,7 +259,7 @@ static unsigned long long sim_wave(const orc_ray* rays, uint32_t count, uint32_t
         if (!noWork) refill = exhausted ? (nDone >= P->refillMin) : ((nDone + nEmpty) >= P->refillMin);
         if (draining && P->split && nDone) refill = 1;      /* drain mode: finished rays are written out at once so the lane can help */
         if (refill) {
-            if (draining) { ++drain; st->drainRefills++; } else st->mainIters++;
+            if (draining) { ++drain; st->drainRefills++; st->drainIters += 150; } else st->mainIters++;
             for (int i = 0; i < WAVE; ++i) if (lanes[i].node == K_DONE) {
                 if (verify) check(rays, lanes[i].rayIdx, &lanes[i].hit, st);
                 lanes[i].node = K_EMPTY;
@@ -318,7 +319,16 @@ static unsigned long long sim_wave(const orc_ray* rays, uint32_t count, uint32_t
         const int thin = nActive <= P->tailActive;
         int doLeaf = nLeaf >= P->leafMin || nInner == 0 || (nLeaf * 4 >= nActive);
         int doInner = nInner != 0 && (!doLeaf || thin);
-        if (draining && P->both) { doLeaf = nLeaf != 0; doInner = 1; }
+        if (draining && P->both == 1) { doLeaf = nLeaf != 0; doInner = 1; }
+        if (draining && P->both >= 2 && thin) {
+            /* critical-ray-first: the ray that has already done the most steps decides which body runs */
+            int o = -1;
+            for (int l = 0; l < WAVE; ++l) if (lanes[l].node > K_WAIT && (o < 0 || lanes[l].age > lanes[o].age)) o = l;
+            const int oLeaf = is_leaf(&lanes[o]);
+            if (P->both == 2) { doLeaf = oLeaf; doInner = !oLeaf; }
+            else { doLeaf = oLeaf || (nLeaf * 2 >= nActive); doInner = nInner != 0 && (!oLeaf || nInner * 2 >= nActive); }
+        }
+        if (draining) st->drainIters += 40 + (doLeaf ? 140 : 0) + (doInner ? 65 : 0);
         if (draining) { drain += (doLeaf ? 1 : 0) + (doInner ? 1 : 0); st->drainBodies += (doLeaf ? 1 : 0) + (doInner ? 1 : 0); } else st->mainIters += (doLeaf ? 1 : 0) + (doInner ? 1 : 0);
         /* snapshot the classes first: a lane does one step per body */
         int wasLeaf[WAVE], wasInner[WAVE];
@@ -327,6 +337,7 @@ static unsigned long long sim_wave(const orc_ray* rays, uint32_t count, uint32_t
         if (doInner) for (int l = 0; l < WAVE; ++l) if (lanes[l].node > K_WAIT && is_inner(&lanes[l]) && (wasInner[l] || doLeaf)) lane_inner(&lanes[l], st, draining);
     }
     free(lanes);
+    { const unsigned long long c = st->drainIters - cost0; if (c > st->drainMax) st->drainMax = c; }
     return drain;
 }
 
@@ -355,8 +366,8 @@ int main(int argc, char** argv) {
         sum += d; if (d > mx) mx = d;
     }
     printf("{\"split\": %d, \"minStack\": %d, \"minAge\": %d, \"stash\": %d, \"both\": %d, \"waves\": %d, \"rays\": %llu, \"main_iters_per_wave\": %.1f, \"drain_iters_mean\": %.1f, \"drain_iters_max\": %llu, "
-           "\"donations\": %llu, \"split_steps\": %llu, \"folded_rays\": %llu, \"fallbacks\": %llu, \"drain_visits\": %llu, \"main_visits\": %llu, \"mono_violations\": %llu, \"mismatches\": %llu, \"drain_refills_per_wave\": %.1f, \"drain_bodies_per_wave\": %.1f, \"split_steps_per_wave\": %.1f}\n",
+           "\"donations\": %llu, \"split_steps\": %llu, \"folded_rays\": %llu, \"fallbacks\": %llu, \"drain_visits\": %llu, \"main_visits\": %llu, \"mono_violations\": %llu, \"mismatches\": %llu, \"drain_refills_per_wave\": %.1f, \"drain_bodies_per_wave\": %.1f, \"split_steps_per_wave\": %.1f, \"drain_cost_mean\": %.0f, \"drain_cost_max\": %llu}\n",
            P.split, P.minStack, P.minAge, P.stash, P.both, nw, st.rays, (double)st.mainIters / nw, (double)sum / nw, mx, st.donations, st.splitSteps, st.foldedRays, st.fallbacks,
-           st.drainVisits, st.mainVisits, st.monoViol, st.mismatches, (double)st.drainRefills / nw, (double)st.drainBodies / nw, (double)st.splitSteps / nw);
+           st.drainVisits, st.mainVisits, st.monoViol, st.mismatches, (double)st.drainRefills / nw, (double)st.drainBodies / nw, (double)st.splitSteps / nw, (double)st.drainIters / nw, st.drainMax);
     return st.mismatches ? 1 : 0;
 }

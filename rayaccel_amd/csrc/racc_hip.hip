@@ -418,9 +418,10 @@ __device__ __forceinline__ float4 asFloat4(u32x4 v) {
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int BLOCK, int LDS_LEVELS, bool SPILL, bool STATS, bool BUF = true, bool TOS = true, bool XQ = false, bool SOA = false>
+template <int BLOCK, int LDS_LEVELS, bool SPILL, bool STATS, bool BUF = true, bool TOS = true, bool XQ = false, bool SOA = false, bool PF = false>
 __global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) {
     __shared__ uint32_t lds[LDS_LEVELS * BLOCK];
+    __shared__ uint32_t pfSink[PF ? 2 * BLOCK : 1];     // PF: where the touch loads land (never read)
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     uint32_t* const myLds = lds + tid;
@@ -623,6 +624,22 @@ __global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) 
                     d1 = np[1]; d2 = np[2]; d3 = np[3];
                     asm volatile("" :: "v"(k2.x), "v"(k2.y));   // keep the child-ref load up here, in flight with the boxes (the
                     kids.x = k2.x; kids.y = k2.y;               // compiler otherwise sinks it behind the slab tests: +1 round trip)
+                    // The whole record must have arrived before the touches go out, on every path: otherwise the compiler parks
+                    // its vmcnt(0) for d1..d3 behind the branch, where it would wait for the touches as well.
+                    if (PF) asm volatile("" :: "v"(d1.x), "v"(d2.x), "v"(d3.w));
+                    if (PF && nActive <= a.tailActive) {
+                        // Thin wave = latency-bound: pull both children's lines towards this CU while the slab tests run.
+                        // LDS-DMA loads have no register destination, so nothing has to stay reserved while they are in flight
+                        // and the compiler does not wait for them before the next record's own wait (where they are older).
+                        const char* pa = int(kids.x) < 0 ? reinterpret_cast<const char*>(a.nodes) + (size_t(kids.x & 0x7FFFFFFFu) << 6)
+                                                         : reinterpret_cast<const char*>(a.pairs) + size_t(kids.x & 0xFFFFFFu) * 48u;
+                        const char* pb = int(kids.y) < 0 ? reinterpret_cast<const char*>(a.nodes) + (size_t(kids.y & 0x7FFFFFFFu) << 6)
+                                                         : reinterpret_cast<const char*>(a.pairs) + size_t(kids.y & 0xFFFFFFu) * 48u;
+                        typedef const __attribute__((address_space(1))) void* gptr_t;
+                        typedef __attribute__((address_space(3))) void* lptr_t;
+                        __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(pfSink + (tid & ~63u)), 4, 0, 0);
+                        __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(pfSink + BLOCK + (tid & ~63u)), 4, 0, 0);
+                    }
                 }
                 const float tRay = r.tFar;
                 float tFirst, tLast;
@@ -1110,6 +1127,7 @@ const Variant kVariants[] = {
     {256, 26, 0, traverseKernelV2<256, 26, false, false, false, false, true>, true, true}, // 25: variant 22 + per-XCD ray queues (measured slower: DESIGN.md §3)
     {256, 26, 0, traverseKernelV2<256, 26, false, true, false, false, false>, true, true}, // 26: variant 22 + statistics (debug)
     {256, 26, 0, traverseKernelV2<256, 26, false, false, false, false, false, true>, true, true}, // 27: variant 22 with the node records transposed to SoA planes (ablation: DESIGN.md §2)
+    {256, 26, 0, traverseKernelV2<256, 26, false, false, false, false, false, false, true>, true, true}, // 28: variant 22 + touch loads of both children in thin waves
 };
 constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kSoaVariant = 27;
