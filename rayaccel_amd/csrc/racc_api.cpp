@@ -20,6 +20,7 @@
 
 #include <xmmintrin.h>
 #include <pmmintrin.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -79,6 +80,23 @@ void complainHip(const char* what) { std::fprintf(stderr, "RayAccelerator: %s (%
 void setFlushToZero() {   // reference Threading.h:78-79, RayAccelerator.cpp:419-420
     _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON);
     _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON);
+}
+
+// CPUs this process may actually use: the affinity mask, capped by the cgroup-v2 CPU quota (a container with a
+// 16-CPU quota on a 256-thread host must not start 32 shading threads: they would only be throttled).
+unsigned usableCpus() {
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = unsigned(CPU_COUNT(&set));
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long quota = 0, period = 0;
+        if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+            const unsigned q = unsigned((quota + period - 1) / period);
+            if (q && q < n) n = q;
+        }
+        std::fclose(f);
+    }
+    return n ? n : 1u;
 }
 
 uint32_t takeOutputStream(Context* c) {   // reference :60,108: a partly filled stream first, else an empty one
@@ -226,8 +244,7 @@ Configuration defaultConfiguration(GpuContext gpuContext) {   // reference :429-
     Configuration cfg{};
     cfg.gpuContext = gpuContext;
     cfg.allowCpuTracing = false;
-    unsigned hw = std::thread::hardware_concurrency();
-    if (!hw) hw = 1;
+    const unsigned hw = usableCpus();
     cfg.cpuThreads = std::min(hw > 2 ? hw - 2 : 1u, 32u);   // callbacks only; leave room for the submission threads
     cfg.gpuSubmissionThreads = 2;                           // one launch + one copy in flight
     cfg.maxRaysInFlight = 4u << 20;                         // reference 262,144 = 29 x its iGPU's 8,960 lanes; MI355X holds 327,680+
