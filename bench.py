@@ -180,6 +180,25 @@ def main():
             ctx.intersect(scene, env, bounce, res_host)
         extras["host_buffers_pcie_inclusive_mrays_per_s"] = round(3 * n / (time.perf_counter() - t1) / 1e6, 1)
 
+        # BASELINE configs[4]: the path tracer, 1920x1080, end to end on this GPU.  Device-resident consumer (generation and
+        # shading kernels around racc_hip_intersect_device) at 64 spp; the reference-shaped consumer (spawn/shade callbacks on
+        # host threads through racc::render, PCIe both ways) at 8 spp.  Both render the same image (tests/test_gpu_pathtracer.py).
+        if world == 1 and full:
+            import tempfile
+            from rayaccel_amd.engine import path_trace
+            tmp = tempfile.NamedTemporaryFile(suffix=".bin", delete=False)
+            tmp.close()
+            try:
+                synth.write_scene_bin(tmp.name, sc, viewport=(1920, 1080))
+                _, sg = path_trace(tmp.name, 1920, 1080, 0, 64, device=device, shading="gpu")
+                _, sh = path_trace(tmp.name, 1920, 1080, 0, 8, device=device, shading="cpu", cpu_threads=usable_cores())
+                extras["path_tracer_1080p"] = {
+                    "gpu_shading_64spp": {"mrays_per_s": round(sg["rays_traced"] / sg["seconds"] / 1e6, 1), "seconds": round(sg["seconds"], 4), "rays": int(sg["rays_traced"])},
+                    "host_shading_8spp": {"mrays_per_s": round(sh["rays_traced"] / sh["seconds"] / 1e6, 1), "seconds": round(sh["seconds"], 4), "rays": int(sh["rays_traced"]),
+                                          "shade_threads": int(sh["threads"])}}
+            finally:
+                os.unlink(tmp.name)
+
     # ---- roofline + CPU baseline (rank 0) --------------------------------------------------------
     roofline, cpu_baseline = None, None
     if rank == 0:

@@ -1,0 +1,237 @@
+// pt_device.hip — device-resident path-tracing consumer of the intersect path (BASELINE.json configs[4]).
+//
+// The reference's renderer (Renderer/PathTracingRenderer.cpp) shades on CPU threads through the spawn/shade callbacks
+// and ships every ray batch to the GPU and back; pathtracer.cpp keeps that shape (it is what a user of the reference's
+// API writes) and is bound by host shading: 16 shading threads keep the MI355X 14 % busy.  This consumer is the
+// MI355X-shaped alternative: rays, hits and path payloads never leave HBM.  Per batch of samples
+//     ptGenKernel      camera rays for every pixel x sample of the batch        (Camera.cpp:55-85)
+//     repeat: racc_hip_intersect_device (the engine, device-pointer entry of the C-ABI)
+//             ptShadeKernel: misses add weight x radiance to the fixed-point frame buffer, hits sample the material and
+//             write the next ray through a wave-aggregated (ballot + one atomic per wave) compaction   (…Renderer.cpp:72-566)
+// until no path is alive.  The per-ray arithmetic is pt_shade.h, the same source the host consumer compiles, the RNG is
+// keyed by (pixel, sample, depth) and the frame buffer is integer, so both consumers render the SAME image bit for bit
+// (tests/test_gpu_pathtracer.py) — the host consumer is this kernel's oracle.
+// Compiled with -fgpu-flush-denormals-to-zero: the host callbacks run with FTZ/DAZ set (Threading.h:78-79).
+
+#include <hip/hip_runtime.h>
+
+#include "pt_scene.h"
+#include "pt_shade.h"
+#include "racc_hip.h"
+
+#include <chrono>
+#include <cstdio>
+#include <vector>
+
+extern "C" {
+
+typedef struct racc_pt_stats {     // same layout as pathtracer.cpp's
+    uint64_t rays_traced;
+    uint64_t primary_rays;
+    double seconds;                // wall time of the render loop (scene build/upload excluded, as in racc_pt_render_file)
+    uint32_t tiles_x, tiles_y;
+    uint32_t max_depth;
+    uint32_t threads;              // 0: nothing is shaded on the host
+    uint32_t triangles;
+    uint32_t reserved;             // bounce rounds executed
+} racc_pt_stats;
+
+// Renders samples [spp_first, spp_first + spp_count) of every pixel and writes the SUM of their radiance (not the mean)
+// as rgb doubles, row-major width*height*3.  samples_per_batch 0 => 8.  Returns 0 on success.
+int racc_ptdev_render_file(const char* scene_bin, int device, uint32_t width, uint32_t height,
+                           uint32_t spp_first, uint32_t spp_count, uint32_t max_depth /* 0 = from the file */,
+                           uint32_t samples_per_batch, double* rgb_sum, racc_pt_stats* stats);
+}
+
+namespace {
+
+using namespace ptshade;
+
+// Pixels are walked in 8x8 blocks so that the 64 rays of a wave start out as one coherent bundle.
+__global__ void __launch_bounds__(256) ptGenKernel(Camera cam, uint32_t width, uint32_t regionW, uint32_t regionH,
+                                                   uint32_t sampleFirst, uint32_t samples,
+                                                   RayRec* rays, PathRec* paths, uint32_t* sampleIdx) {
+    const uint32_t perSample = regionW * regionH;
+    const uint64_t total = uint64_t(perSample) * samples;
+    for (uint64_t i = uint64_t(blockIdx.x) * 256u + threadIdx.x; i < total; i += uint64_t(gridDim.x) * 256u) {
+        const uint32_t s = uint32_t(i / perSample), pi = uint32_t(i % perSample);
+        const uint32_t block = pi >> 6, within = pi & 63u, blocksX = regionW >> 3;
+        const uint32_t x = (block % blocksX) * 8u + (within & 7u), y = (block / blocksX) * 8u + (within >> 3);
+        const uint32_t pixel = y * width + x;
+        RayRec ray; PathRec path;
+        primaryRay(cam, x, y, pixel, sampleFirst + s, ray, path);
+        rays[i] = ray; paths[i] = path; sampleIdx[i] = sampleFirst + s;
+    }
+}
+
+__global__ void __launch_bounds__(256) ptShadeKernel(SceneView view, Materials mat, uint32_t maxDepth,
+                                                     const RayRec* rays, const HitRec* hits, const PathRec* paths, const uint32_t* sampleIdx,
+                                                     uint32_t count, RayRec* outRays, PathRec* outPaths, uint32_t* outSample,
+                                                     uint32_t* outCount, unsigned long long* frame) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+        const uint32_t i = base + threadIdx.x;
+        bool alive = false;
+        RayRec nextRay; PathRec nextPath; uint32_t sample = 0;
+        if (i < count) {
+            const HitRec hit = hits[i];
+            const PathRec path = paths[i];
+            if (hit.triangle == 0xFFFFFFFFu) {
+                long long add[3]; bool valid[3];
+                missContribution(hit, path, add, valid);
+                const uint32_t pixel = path.pixelDepth & 0xFFFFFFu;
+                for (int ch = 0; ch < 3; ++ch)
+                    if (valid[ch] && add[ch] != 0) atomicAdd(frame + size_t(pixel) * 3 + ch, (unsigned long long)add[ch]);
+            } else {
+                sample = sampleIdx[i];
+                alive = shadeHit(view, mat, maxDepth, rays[i], hit, path, sample, nextRay, nextPath);
+            }
+        }
+        // wave-aggregated compaction: one atomic per wave, ranks from the ballot
+        const unsigned long long mask = __ballot(alive);
+        if (mask) {
+            uint32_t first = 0;
+            if (lane == uint32_t(__ffsll((long long)mask) - 1)) first = atomicAdd(outCount, uint32_t(__popcll(mask)));
+            first = __shfl(first, __ffsll((long long)mask) - 1);
+            if (alive) {
+                const uint32_t slot = first + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+                outRays[slot] = nextRay; outPaths[slot] = nextPath; outSample[slot] = sample;
+            }
+        }
+    }
+}
+
+#define PT_HIP(call)                                                                                             \
+    do {                                                                                                         \
+        hipError_t e_ = (call);                                                                                  \
+        if (e_ != hipSuccess) { std::fprintf(stderr, "racc_ptdev: %s: %s\n", #call, hipGetErrorString(e_)); rc = -4; goto done; } \
+    } while (0)
+#define PT_RACC(call)                                                                                            \
+    do {                                                                                                         \
+        if ((call) != RACC_HIP_OK) { std::fprintf(stderr, "racc_ptdev: %s: %s\n", #call, racc_hip_last_error()); rc = -3; goto done; } \
+    } while (0)
+
+}  // namespace
+
+extern "C" int racc_ptdev_render_file(const char* scene_bin, int device, uint32_t width, uint32_t height,
+                                      uint32_t spp_first, uint32_t spp_count, uint32_t max_depth,
+                                      uint32_t samples_per_batch, double* rgb_sum, racc_pt_stats* stats) {
+    if (!scene_bin || !rgb_sum || !width || !height || !spp_count) return -1;
+    if (uint64_t(width) * height > (1u << 24)) { std::fprintf(stderr, "racc_ptdev: the payload keeps the pixel index in 24 bits (LightPath.h:16)\n"); return -1; }
+    ptscene::Scene sc;
+    if (int lrc = ptscene::load(scene_bin, width, height, sc)) return lrc;
+    const uint32_t T = sc.hdr.triangleCount, V = sc.hdr.vertexCount;
+    const uint32_t tilesX = width / 128, tilesY = height / 128;          // TiledRenderer.cpp:20-22: whole 128x128 tiles only
+    const uint32_t regionW = tilesX * 128, regionH = tilesY * 128;
+    const uint32_t depthLimit = max_depth ? max_depth : sc.hdr.maxDepth;
+    const uint64_t perSample = uint64_t(regionW) * regionH;
+    uint32_t S = samples_per_batch ? samples_per_batch : 8;   // 8 x 1.97M rays at 1080p: 1.9 GB of buffers, 6 host syncs per 8 spp
+    if (S > spp_count) S = spp_count;
+    while (S > 1 && perSample * S > (1ull << 30)) --S;                    // ray counts are 32-bit in the C-ABI
+
+    int rc = 0;
+    racc_hip_ctx* ctx = nullptr; racc_host_scene* host = nullptr; racc_hip_scene* scene = nullptr; racc_hip_env* env = nullptr;
+    hipStream_t stream = nullptr;
+    uint32_t *dIndices = nullptr, *dSample[2] = {nullptr, nullptr}, *dCount = nullptr, *hCount = nullptr;
+    uint16_t* dMaterials = nullptr;
+    float *dNormals = nullptr, *dVertices = nullptr;
+    RayRec* dRays[2] = {nullptr, nullptr}; PathRec* dPaths[2] = {nullptr, nullptr}; HitRec* dHits = nullptr;
+    unsigned long long* dFrame = nullptr;
+    uint64_t raysTraced = 0, primaries = 0; uint32_t rounds = 0;
+    double seconds = 0.0;
+    const size_t cap = size_t(perSample) * S;
+    const size_t frameWords = size_t(width) * height * 3;
+    if (perSample == 0) {   // nothing to render (viewport smaller than one tile): an all-zero image, like the host consumer
+        for (size_t i = 0; i < frameWords; ++i) rgb_sum[i] = 0.0;
+        goto fill;
+    }
+    {
+        racc_hip_options opts{};
+        opts.struct_size = sizeof(opts);
+        opts.lanes = 1;
+        PT_RACC(racc_hip_create(device, &opts, &ctx));
+        PT_RACC(racc_host_scene_build(sc.vertices.data(), V, sc.indices.data(), T * 3, &host));
+        const void *nodes = nullptr, *pairs = nullptr; const uint32_t* remap = nullptr;
+        uint32_t nNodes = 0, nPairsPadded = 0, nPairs = 0, nRemap = 0;
+        PT_RACC(racc_host_scene_blobs(host, &nodes, &nNodes, &pairs, &nPairsPadded, &nPairs, &remap, &nRemap));
+        PT_RACC(racc_hip_scene_upload(ctx, nodes, nNodes, pairs, nPairsPadded, remap, nRemap, &scene));
+        racc_host_scene_free(host); host = nullptr;
+        PT_RACC(racc_hip_env_upload(ctx, sc.env.data(), sc.hdr.environmentWidth, sc.hdr.environmentHeight, &env));
+
+        PT_HIP(hipSetDevice(device));
+        PT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        PT_HIP(hipMalloc(&dIndices, size_t(T) * 12)); PT_HIP(hipMemcpy(dIndices, sc.indices.data(), size_t(T) * 12, hipMemcpyHostToDevice));
+        PT_HIP(hipMalloc(&dMaterials, size_t(T) * 2)); PT_HIP(hipMemcpy(dMaterials, sc.triangleMaterials.data(), size_t(T) * 2, hipMemcpyHostToDevice));
+        PT_HIP(hipMalloc(&dNormals, size_t(V) * 16)); PT_HIP(hipMemcpy(dNormals, sc.normals.data(), size_t(V) * 16, hipMemcpyHostToDevice));
+        PT_HIP(hipMalloc(&dVertices, size_t(V) * 16)); PT_HIP(hipMemcpy(dVertices, sc.vertices.data(), size_t(V) * 16, hipMemcpyHostToDevice));
+        for (int k = 0; k < 2; ++k) {
+            PT_HIP(hipMalloc(&dRays[k], cap * sizeof(RayRec)));
+            PT_HIP(hipMalloc(&dPaths[k], cap * sizeof(PathRec)));
+            PT_HIP(hipMalloc(&dSample[k], cap * 4));
+        }
+        PT_HIP(hipMalloc(&dHits, cap * sizeof(HitRec)));
+        PT_HIP(hipMalloc(&dCount, 4));
+        PT_HIP(hipHostMalloc(&hCount, 4));
+        PT_HIP(hipMalloc(&dFrame, frameWords * 8));
+        PT_HIP(hipMemset(dFrame, 0, frameWords * 8));
+        PT_HIP(hipDeviceSynchronize());
+
+        const SceneView view{dIndices, dMaterials, dNormals, dVertices, T};
+        hipDeviceProp_t prop;
+        PT_HIP(hipGetDeviceProperties(&prop, device));
+        const uint32_t maxBlocks = uint32_t(prop.multiProcessorCount) * 8u;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t s0 = 0; s0 < spp_count; s0 += S) {
+            const uint32_t ns = (spp_count - s0 < S) ? spp_count - s0 : S;
+            uint32_t n = uint32_t(perSample * ns);
+            int cur = 0;
+            {
+                const uint32_t blocks = (n + 255u) / 256u < maxBlocks ? (n + 255u) / 256u : maxBlocks;
+                hipLaunchKernelGGL(ptGenKernel, dim3(blocks), dim3(256), 0, stream, sc.cam, width, regionW, regionH, spp_first + s0, ns,
+                                   dRays[cur], dPaths[cur], dSample[cur]);
+                PT_HIP(hipGetLastError());
+            }
+            primaries += n;
+            while (n) {
+                PT_RACC(racc_hip_intersect_device(ctx, scene, env, dRays[cur], dHits, n, 0, stream));
+                raysTraced += n; ++rounds;
+                PT_HIP(hipMemsetAsync(dCount, 0, 4, stream));
+                const uint32_t blocks = (n + 255u) / 256u < maxBlocks ? (n + 255u) / 256u : maxBlocks;
+                hipLaunchKernelGGL(ptShadeKernel, dim3(blocks), dim3(256), 0, stream, view, sc.mat, depthLimit,
+                                   dRays[cur], dHits, dPaths[cur], dSample[cur], n, dRays[cur ^ 1], dPaths[cur ^ 1], dSample[cur ^ 1], dCount, dFrame);
+                PT_HIP(hipGetLastError());
+                PT_HIP(hipMemcpyAsync(hCount, dCount, 4, hipMemcpyDeviceToHost, stream));
+                PT_HIP(hipStreamSynchronize(stream));
+                n = *hCount;
+                cur ^= 1;
+            }
+        }
+        PT_HIP(hipStreamSynchronize(stream));
+        seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::vector<long long> frame(frameWords);
+        PT_HIP(hipMemcpy(frame.data(), dFrame, frameWords * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < frameWords; ++i) rgb_sum[i] = double(frame[i]) / kFixed;
+    }
+fill:
+    if (stats) {
+        stats->rays_traced = raysTraced; stats->primary_rays = primaries; stats->seconds = seconds;
+        stats->tiles_x = tilesX; stats->tiles_y = tilesY; stats->max_depth = depthLimit; stats->threads = 0;
+        stats->triangles = T; stats->reserved = rounds;
+    }
+done:
+    if (host) racc_host_scene_free(host);
+    for (int k = 0; k < 2; ++k) { if (dRays[k]) hipFree(dRays[k]); if (dPaths[k]) hipFree(dPaths[k]); if (dSample[k]) hipFree(dSample[k]); }
+    if (dHits) hipFree(dHits);
+    if (dCount) hipFree(dCount);
+    if (hCount) hipHostFree(hCount);
+    if (dFrame) hipFree(dFrame);
+    if (dIndices) hipFree(dIndices);
+    if (dMaterials) hipFree(dMaterials);
+    if (dNormals) hipFree(dNormals);
+    if (dVertices) hipFree(dVertices);
+    if (stream) hipStreamDestroy(stream);
+    if (env) racc_hip_env_free(ctx, env);
+    if (scene) racc_hip_scene_free(ctx, scene);
+    if (ctx) racc_hip_destroy(ctx);
+    return rc;
+}

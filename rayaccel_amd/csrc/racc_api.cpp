@@ -23,6 +23,8 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -69,9 +71,15 @@ struct Context {
     RenderCallbacks currentCallbacks{};
 
     std::vector<std::thread> threads;
+
+    // RACC_PROFILE=1: where the wall time of render() goes (summed over threads), printed by destroy()
+    bool profile = false;
+    std::atomic<uint64_t> nsSpawn{0}, nsShade{0}, nsGpu{0}, nsRender{0}, gpuLaunches{0}, gpuStreams{0}, gpuRays{0};
 };
 
 namespace {
+
+inline uint64_t nowNs() { return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count()); }
 
 void complain(const char* what) { std::fprintf(stderr, "RayAccelerator: %s\n", what); }
 
@@ -128,7 +136,9 @@ bool spawnRays(Context* c, std::unique_lock<std::mutex>& lock, unsigned thread) 
     ++c->cpuBusy;
     lock.unlock();
     const uint32_t before = stream->count;
+    const uint64_t t0 = c->profile ? nowNs() : 0;
     const bool more = cb.spawn(cb.data, thread, stream);
+    if (c->profile) c->nsSpawn += nowNs() - t0;
     const uint32_t added = stream->count - before;
     lock.lock();
     --c->cpuBusy;
@@ -155,7 +165,9 @@ bool shadeRays(Context* c, std::unique_lock<std::mutex>& lock, unsigned thread) 
         RayStream* out = &c->streams[outId];
         lock.unlock();
         const uint32_t before = out->count;
+        const uint64_t t0 = c->profile ? nowNs() : 0;
         cb.shade(cb.data, thread, stream, start, end, out);
+        if (c->profile) c->nsShade += nowNs() - t0;
         const uint32_t added = out->count - before;
         lock.lock();
         c->raysInFlight += added;
@@ -215,8 +227,10 @@ void gpuWorker(Context* c, unsigned lane) {   // reference gpuWorkerThread, :335
         Scene* scene = c->currentScene;
         Environment* env = c->currentEnvironment;
         lock.unlock();
+        const uint64_t t0 = c->profile ? nowNs() : 0;
         const int rc = racc_hip_intersect_streams(c->hip, scene->device, env ? env->device : nullptr, uint32_t(ids.size()),
                                                   rays.data(), results.data(), counts.data(), lane);
+        if (c->profile) { c->nsGpu += nowNs() - t0; ++c->gpuLaunches; c->gpuStreams += ids.size(); c->gpuRays += total; }
         if (rc != RACC_HIP_OK) {                         // the reference ignores device errors here (:393-403); we do not
             complainHip("GPU intersection failed");
             std::abort();
@@ -268,6 +282,7 @@ Context* createContext(Configuration cfg) {
     Context* c = new (std::nothrow) Context();
     if (!c) { complain("Unable to allocate memory."); return nullptr; }
     c->configuration = cfg;
+    c->profile = std::getenv("RACC_PROFILE") != nullptr;
 
     racc_hip_options opts{};
     opts.struct_size = sizeof(opts);
@@ -322,6 +337,17 @@ void destroy(Context* c) {   // reference :761-788
     }
     c->wake.notify_all();
     for (std::thread& t : c->threads) t.join();
+    if (c->profile) {
+        const double wall = double(c->nsRender.load()) * 1e-9;
+        std::fprintf(stderr, "RayAccelerator profile: render %.3f s | spawn %.3f + shade %.3f thread-s over %u cpu threads (%.0f %% busy) | "
+                             "gpu path %.3f thread-s over %u lanes (%.0f %% busy), %llu launches, %.1f streams and %.0f rays per launch\n",
+                     wall, double(c->nsSpawn.load()) * 1e-9, double(c->nsShade.load()) * 1e-9, c->configuration.cpuThreads,
+                     wall > 0 ? 100.0 * double(c->nsSpawn.load() + c->nsShade.load()) * 1e-9 / (wall * c->configuration.cpuThreads) : 0.0,
+                     double(c->nsGpu.load()) * 1e-9, c->configuration.gpuSubmissionThreads,
+                     wall > 0 ? 100.0 * double(c->nsGpu.load()) * 1e-9 / (wall * c->configuration.gpuSubmissionThreads) : 0.0,
+                     (unsigned long long)c->gpuLaunches.load(), c->gpuLaunches ? double(c->gpuStreams.load()) / double(c->gpuLaunches.load()) : 0.0,
+                     c->gpuLaunches ? double(c->gpuRays.load()) / double(c->gpuLaunches.load()) : 0.0);
+    }
     if (c->blockPinned) racc_hip_unregister_host(c->hip, c->block);
     racc_hip_destroy(c->hip);
     std::free(c->block);
@@ -382,6 +408,7 @@ void destroy(Environment* e) {   // reference Environment.cpp:62-67
 }
 
 Stats render(Context* c, Scene* scene, Environment* environment, RenderCallbacks callbacks) {   // reference :738-759
+    const uint64_t t0 = c->profile ? nowNs() : 0;
     std::unique_lock<std::mutex> lock(c->mutex);
     c->currentScene = scene;
     c->currentEnvironment = environment;
@@ -392,6 +419,7 @@ Stats render(Context* c, Scene* scene, Environment* environment, RenderCallbacks
     Stats stats{};
     stats.raysTraced = c->rayCount;
     c->rayCount = 0;
+    if (c->profile) c->nsRender += nowNs() - t0;
     return stats;
 }
 

@@ -21,7 +21,8 @@ from .synth import RAY_DTYPE, RESULT_DTYPE, INVALID_TRIANGLE  # noqa: F401  (re-
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libracc_hip.so")
 API_LIB_PATH = os.path.join(_HERE, "librayaccelerator.so")       # racc:: C++ interface over the C-ABI
-PT_LIB_PATH = os.path.join(_HERE, "libracc_pathtracer.so")       # path-tracing consumer (BASELINE configs[4])
+PT_LIB_PATH = os.path.join(_HERE, "libracc_pathtracer.so")       # path-tracing consumer (BASELINE configs[4]), host shading
+PTDEV_LIB_PATH = os.path.join(_HERE, "libracc_ptdev.so")         # the same consumer with generation/shading kernels on the GPU
 CSRC = os.path.join(_HERE, "csrc")
 
 BVH2_NODE_DTYPE = np.dtype([("kind", "<u4"), ("parent", "<u4"), ("first", "<u4"), ("last", "<u4"),
@@ -96,10 +97,11 @@ _lib = None
 
 def build_library(force=False):
     """Compile libracc_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("racc_hip.hip", "scene_build.cpp", "racc_api.cpp", "pathtracer.cpp", "Makefile")]
+    srcs = [os.path.join(CSRC, f) for f in ("racc_hip.hip", "scene_build.cpp", "racc_api.cpp", "pathtracer.cpp", "pt_device.hip", "pt_shade.h",
+                                                 "pt_scene.h", "Makefile")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("racc_hip.h", "RayAccelerator.h")]
     srcs.append(os.path.join(_HERE, "..", "tests", "cpp", "render_check.cpp"))
-    outs = [LIB_PATH, API_LIB_PATH, PT_LIB_PATH, os.path.join(_HERE, "..", "tests", "cpp", "render_check")]
+    outs = [LIB_PATH, API_LIB_PATH, PT_LIB_PATH, PTDEV_LIB_PATH, os.path.join(_HERE, "..", "tests", "cpp", "render_check")]
     stale = any(not os.path.exists(o) for o in outs) or any(os.path.getmtime(s) > min(os.path.getmtime(o) for o in outs) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", CSRC])
@@ -336,17 +338,26 @@ class PathTraceStats(C.Structure):
                 ("triangles", C.c_uint32), ("reserved", C.c_uint32)]
 
 
-def path_trace(scene_bin, width, height, spp_first, spp_count, device=0, max_depth=0, cpu_threads=0):
-    """Render samples [spp_first, spp_first+spp_count) of a reference-format scene file with the path-tracing consumer
-    (rayaccel_amd/csrc/pathtracer.cpp).  Returns (sum of radiance [H,W,3] float64, stats dict)."""
+def path_trace(scene_bin, width, height, spp_first, spp_count, device=0, max_depth=0, cpu_threads=0, shading="cpu", samples_per_batch=0):
+    """Render samples [spp_first, spp_first+spp_count) of a reference-format scene file with the path-tracing consumer.
+    shading="cpu": spawn/shade callbacks on host threads through racc::render (rayaccel_amd/csrc/pathtracer.cpp, the
+    reference's shape); shading="gpu": generation, shading and compaction kernels around racc_hip_intersect_device, rays
+    never leave HBM (rayaccel_amd/csrc/pt_device.hip).  Both render the same image bit for bit.
+    Returns (sum of radiance [H,W,3] float64, stats dict)."""
     load_library()
-    lib = C.CDLL(PT_LIB_PATH)
-    lib.racc_pt_render_file.restype = C.c_int
-    lib.racc_pt_render_file.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
-                                        C.c_void_p, C.POINTER(PathTraceStats)]
     img = np.zeros((height, width, 3), np.float64)
     st = PathTraceStats()
-    rc = lib.racc_pt_render_file(os.fsencode(scene_bin), device, width, height, spp_first, spp_count, max_depth, cpu_threads, _ptr(img), C.byref(st))
+    if shading == "cpu":
+        lib = C.CDLL(PT_LIB_PATH)
+        fn, last = lib.racc_pt_render_file, cpu_threads
+    elif shading == "gpu":
+        lib = C.CDLL(PTDEV_LIB_PATH)
+        fn, last = lib.racc_ptdev_render_file, samples_per_batch
+    else:
+        raise ValueError("shading must be 'cpu' or 'gpu'")
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(PathTraceStats)]
+    rc = fn(os.fsencode(scene_bin), device, width, height, spp_first, spp_count, max_depth, last, _ptr(img), C.byref(st))
     if rc != 0:
-        raise RaccError(rc, "racc_pt_render_file failed")
+        raise RaccError(rc, "path tracer (%s shading) failed" % shading)
     return img, {f: getattr(st, f) for f, _ in PathTraceStats._fields_}

@@ -54,6 +54,28 @@ def test_energy_bounds_and_primary_misses(scene_file, small_scene):
     np.testing.assert_allclose(mean[bright][:, 1] / mean[bright][:, 0], 2.0, rtol=1e-3)          # grey materials keep the sky's colour ratio
 
 
+def test_device_consumer_renders_the_same_image(scene_file):
+    """pt_device.hip (generation + shading kernels, rays resident in HBM) against pathtracer.cpp (host callbacks): the same
+    pt_shade.h arithmetic, the same counter RNG, an integer frame buffer -> identical frames and ray counts."""
+    cpu, sc = path_trace(scene_file, 256, 256, 0, 3, shading="cpu")
+    gpu, sg = path_trace(scene_file, 256, 256, 0, 3, shading="gpu")
+    assert sg["rays_traced"] == sc["rays_traced"] and sg["primary_rays"] == sc["primary_rays"]
+    assert np.array_equal(cpu, gpu)
+    one, s1 = path_trace(scene_file, 256, 256, 0, 3, shading="gpu", samples_per_batch=1)      # batching does not matter
+    assert np.array_equal(one, gpu) and s1["rays_traced"] == sg["rays_traced"]
+    lo, _ = path_trace(scene_file, 256, 256, 0, 1, shading="gpu")
+    hi, _ = path_trace(scene_file, 256, 256, 1, 2, shading="cpu")                                # shards from different consumers add up
+    assert np.array_equal(lo + hi, gpu)
+
+
+def test_device_consumer_whole_tiles(scene_file):
+    img, st = path_trace(scene_file, 300, 200, 0, 2, shading="gpu")
+    assert (st["tiles_x"], st["tiles_y"]) == (2, 1) and st["primary_rays"] == 2 * 2 * 128 * 128 and st["threads"] == 0
+    assert not img[128:].any() and not img[:, 256:].any() and img[:128, :256].any()
+    empty, se = path_trace(scene_file, 100, 100, 0, 1, shading="gpu")                            # no whole tile: nothing traced
+    assert not empty.any() and se["rays_traced"] == 0
+
+
 def test_only_whole_tiles_are_rendered(scene_file):
     img, st = path_trace(scene_file, 300, 200, 0, 1)                    # TiledRenderer.cpp:20-22
     assert (st["tiles_x"], st["tiles_y"]) == (2, 1) and st["primary_rays"] == 2 * 128 * 128
