@@ -53,3 +53,15 @@ def test_fails_loudly_without_gpu():
     with pytest.raises(ra.RaccError) as e:
         ra.Context(device=0)
     assert e.value.code == -3 and "no CPU fallback" in str(e.value)
+
+
+def test_consumer_libraries_load_and_export_their_entry_points():
+    """The two path-tracing consumers (host callbacks / device kernels) are separate libraries over the boundary."""
+    for path, sym in ((engine.PT_LIB_PATH, "racc_pt_render_file"), (engine.PTDEV_LIB_PATH, "racc_ptdev_render_file"),
+                      (engine.API_LIB_PATH, None)):
+        assert os.path.exists(path), path
+        lib = C.CDLL(path)
+        if sym:
+            assert hasattr(lib, sym)
+        out = os.popen("ldd %s" % path).read()
+        assert "libracc_hip.so" in out and "oracle" not in out and "torch" not in out
