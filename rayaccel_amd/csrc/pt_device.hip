@@ -7,7 +7,7 @@
 //     ptGenKernel      camera rays for every pixel x sample of the batch        (Camera.cpp:55-85)
 //     repeat: racc_hip_intersect_device (the engine, device-pointer entry of the C-ABI)
 //             ptShadeKernel: misses add weight x radiance to the fixed-point frame buffer, hits sample the material and
-//             write the next ray through a wave-aggregated (ballot + one atomic per wave) compaction   (…Renderer.cpp:72-566)
+//             write the next ray through a workgroup-aggregated (ballots + LDS + one atomic per 1024 rays) compaction   (…Renderer.cpp:72-566)
 // until no path is alive.  The per-ray arithmetic is pt_shade.h, the same source the host consumer compiles, the RNG is
 // keyed by (pixel, sample, depth) and the frame buffer is integer, so both consumers render the SAME image bit for bit
 // (tests/test_gpu_pathtracer.py) — the host consumer is this kernel's oracle.
@@ -64,12 +64,19 @@ __global__ void __launch_bounds__(256) ptGenKernel(Camera cam, uint32_t width, u
     }
 }
 
-__global__ void __launch_bounds__(256) ptShadeKernel(SceneView view, Materials mat, uint32_t maxDepth,
+// Workgroups of 1024 threads: the compaction counter is ONE address, and same-address atomics retire at roughly one per
+// 10 ns on this part — one atomic per wave (4.8 M of them for a 1080p x 64 spp frame) made this kernel cost 50 ms, a third
+// of the frame.  Wave ballots -> 16 per-wave counts in LDS -> one atomic per workgroup: 16x fewer.
+constexpr int kShadeBlock = 1024;
+
+__global__ void __launch_bounds__(kShadeBlock) ptShadeKernel(const ShadeTri* tris, uint32_t triangleCount, Materials mat, uint32_t maxDepth,
                                                      const RayRec* rays, const HitRec* hits, const PathRec* paths, const uint32_t* sampleIdx,
                                                      uint32_t count, RayRec* outRays, PathRec* outPaths, uint32_t* outSample,
                                                      uint32_t* outCount, unsigned long long* frame) {
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+    __shared__ uint32_t waveCount[kShadeBlock / 64];
+    __shared__ uint32_t blockFirst;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t base = blockIdx.x * uint32_t(kShadeBlock); base < count; base += gridDim.x * uint32_t(kShadeBlock)) {
         const uint32_t i = base + threadIdx.x;
         bool alive = false;
         RayRec nextRay; PathRec nextPath; uint32_t sample = 0;
@@ -82,22 +89,30 @@ __global__ void __launch_bounds__(256) ptShadeKernel(SceneView view, Materials m
                 const uint32_t pixel = path.pixelDepth & 0xFFFFFFu;
                 for (int ch = 0; ch < 3; ++ch)
                     if (valid[ch] && add[ch] != 0) atomicAdd(frame + size_t(pixel) * 3 + ch, (unsigned long long)add[ch]);
-            } else {
+            } else if ((path.pixelDepth >> 24) < maxDepth && hit.triangle < triangleCount) {     // PathTracingRenderer.cpp:113-114
                 sample = sampleIdx[i];
-                alive = shadeHit(view, mat, maxDepth, rays[i], hit, path, sample, nextRay, nextPath);
+                const float4* tp = reinterpret_cast<const float4*>(tris + hit.triangle);
+                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];                      // one 64 B record
+                const float n0[3] = {q0.x, q0.y, q0.z}, n1[3] = {q0.w, q1.x, q1.y}, n2[3] = {q1.z, q1.w, q2.x};
+                alive = shadeSurface(mat, rays[i], hit, path, sample, n0, n1, n2, Vec{q2.y, q2.z, q2.w}, __float_as_uint(q3.x), nextRay, nextPath);
             }
         }
-        // wave-aggregated compaction: one atomic per wave, ranks from the ballot
+        // workgroup-aggregated compaction: ballot ranks inside a wave, per-wave counts through LDS, one atomic per workgroup
         const unsigned long long mask = __ballot(alive);
-        if (mask) {
-            uint32_t first = 0;
-            if (lane == uint32_t(__ffsll((long long)mask) - 1)) first = atomicAdd(outCount, uint32_t(__popcll(mask)));
-            first = __shfl(first, __ffsll((long long)mask) - 1);
-            if (alive) {
-                const uint32_t slot = first + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
-                outRays[slot] = nextRay; outPaths[slot] = nextPath; outSample[slot] = sample;
-            }
+        if (lane == 0) waveCount[wave] = uint32_t(__popcll(mask));
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (int w = 0; w < kShadeBlock / 64; ++w) total += waveCount[w];
+            blockFirst = total ? atomicAdd(outCount, total) : 0u;
         }
+        __syncthreads();
+        if (alive) {
+            uint32_t slot = blockFirst + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+            for (uint32_t w = 0; w < wave; ++w) slot += waveCount[w];
+            outRays[slot] = nextRay; outPaths[slot] = nextPath; outSample[slot] = sample;
+        }
+        __syncthreads();     // waveCount / blockFirst are rewritten by the next iteration
     }
 }
 
@@ -132,9 +147,8 @@ extern "C" int racc_ptdev_render_file(const char* scene_bin, int device, uint32_
     int rc = 0;
     racc_hip_ctx* ctx = nullptr; racc_host_scene* host = nullptr; racc_hip_scene* scene = nullptr; racc_hip_env* env = nullptr;
     hipStream_t stream = nullptr;
-    uint32_t *dIndices = nullptr, *dSample[2] = {nullptr, nullptr}, *dCount = nullptr, *hCount = nullptr;
-    uint16_t* dMaterials = nullptr;
-    float *dNormals = nullptr, *dVertices = nullptr;
+    uint32_t *dSample[2] = {nullptr, nullptr}, *dCount = nullptr, *hCount = nullptr;
+    ShadeTri* dTris = nullptr;
     RayRec* dRays[2] = {nullptr, nullptr}; PathRec* dPaths[2] = {nullptr, nullptr}; HitRec* dHits = nullptr;
     unsigned long long* dFrame = nullptr;
     uint64_t raysTraced = 0, primaries = 0; uint32_t rounds = 0;
@@ -160,10 +174,13 @@ extern "C" int racc_ptdev_render_file(const char* scene_bin, int device, uint32_
 
         PT_HIP(hipSetDevice(device));
         PT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        PT_HIP(hipMalloc(&dIndices, size_t(T) * 12)); PT_HIP(hipMemcpy(dIndices, sc.indices.data(), size_t(T) * 12, hipMemcpyHostToDevice));
-        PT_HIP(hipMalloc(&dMaterials, size_t(T) * 2)); PT_HIP(hipMemcpy(dMaterials, sc.triangleMaterials.data(), size_t(T) * 2, hipMemcpyHostToDevice));
-        PT_HIP(hipMalloc(&dNormals, size_t(V) * 16)); PT_HIP(hipMemcpy(dNormals, sc.normals.data(), size_t(V) * 16, hipMemcpyHostToDevice));
-        PT_HIP(hipMalloc(&dVertices, size_t(V) * 16)); PT_HIP(hipMemcpy(dVertices, sc.vertices.data(), size_t(V) * 16, hipMemcpyHostToDevice));
+        {
+            const SceneView hostView{sc.indices.data(), sc.triangleMaterials.data(), sc.normals.data(), sc.vertices.data(), T};
+            std::vector<ShadeTri> tris(T);
+            for (uint32_t t = 0; t < T; ++t) buildShadeTri(hostView, t, tris[t]);
+            PT_HIP(hipMalloc(&dTris, size_t(T) * sizeof(ShadeTri)));
+            PT_HIP(hipMemcpy(dTris, tris.data(), size_t(T) * sizeof(ShadeTri), hipMemcpyHostToDevice));
+        }
         for (int k = 0; k < 2; ++k) {
             PT_HIP(hipMalloc(&dRays[k], cap * sizeof(RayRec)));
             PT_HIP(hipMalloc(&dPaths[k], cap * sizeof(PathRec)));
@@ -176,7 +193,6 @@ extern "C" int racc_ptdev_render_file(const char* scene_bin, int device, uint32_
         PT_HIP(hipMemset(dFrame, 0, frameWords * 8));
         PT_HIP(hipDeviceSynchronize());
 
-        const SceneView view{dIndices, dMaterials, dNormals, dVertices, T};
         hipDeviceProp_t prop;
         PT_HIP(hipGetDeviceProperties(&prop, device));
         const uint32_t maxBlocks = uint32_t(prop.multiProcessorCount) * 8u;
@@ -196,8 +212,9 @@ extern "C" int racc_ptdev_render_file(const char* scene_bin, int device, uint32_
                 PT_RACC(racc_hip_intersect_device(ctx, scene, env, dRays[cur], dHits, n, 0, stream));
                 raysTraced += n; ++rounds;
                 PT_HIP(hipMemsetAsync(dCount, 0, 4, stream));
-                const uint32_t blocks = (n + 255u) / 256u < maxBlocks ? (n + 255u) / 256u : maxBlocks;
-                hipLaunchKernelGGL(ptShadeKernel, dim3(blocks), dim3(256), 0, stream, view, sc.mat, depthLimit,
+                const uint32_t need = (n + uint32_t(kShadeBlock) - 1u) / uint32_t(kShadeBlock);
+                const uint32_t blocks = need < uint32_t(prop.multiProcessorCount) * 2u ? need : uint32_t(prop.multiProcessorCount) * 2u;
+                hipLaunchKernelGGL(ptShadeKernel, dim3(blocks), dim3(kShadeBlock), 0, stream, dTris, T, sc.mat, depthLimit,
                                    dRays[cur], dHits, dPaths[cur], dSample[cur], n, dRays[cur ^ 1], dPaths[cur ^ 1], dSample[cur ^ 1], dCount, dFrame);
                 PT_HIP(hipGetLastError());
                 PT_HIP(hipMemcpyAsync(hCount, dCount, 4, hipMemcpyDeviceToHost, stream));
@@ -225,10 +242,7 @@ done:
     if (dCount) hipFree(dCount);
     if (hCount) hipHostFree(hCount);
     if (dFrame) hipFree(dFrame);
-    if (dIndices) hipFree(dIndices);
-    if (dMaterials) hipFree(dMaterials);
-    if (dNormals) hipFree(dNormals);
-    if (dVertices) hipFree(dVertices);
+    if (dTris) hipFree(dTris);
     if (stream) hipStreamDestroy(stream);
     if (env) racc_hip_env_free(ctx, env);
     if (scene) racc_hip_scene_free(ctx, scene);

@@ -146,29 +146,25 @@ RACC_HD void missContribution(const HitRec& hit, const PathRec& path, long long 
     }
 }
 
-// One surface interaction (PathTracingRenderer.cpp:113-422).  Returns true and fills (nextRay, nextPath) when the path
-// continues.  `sample` is the path's sample index (RNG key).
-RACC_HD bool shadeHit(const SceneView& sc, const Materials& mat, uint32_t maxDepth, const RayRec& ray, const HitRec& hit,
-                      const PathRec& path, uint32_t sample, RayRec& nextRay, PathRec& nextPath) {
+// Unnormalised-orientation geometric normal of a triangle from its three xyzw vertices (the side flip happens per ray).
+RACC_HD Vec geometricNormal(const float* a, const float* b, const float* c) {
+    return normalize(cross(Vec{b[0] - a[0], b[1] - a[1], b[2] - a[2]}, Vec{c[0] - a[0], c[1] - a[1], c[2] - a[2]}));
+}
+
+// One surface interaction (PathTracingRenderer.cpp:113-422) given the triangle's three vertex normals, its geometric
+// normal and its material.  Returns true and fills (nextRay, nextPath) when the path continues.  `sample` is the path's
+// sample index (RNG key).  The caller has already checked depth < maxDepth and the triangle index (:113-114).
+RACC_HD bool shadeSurface(const Materials& mat, const RayRec& ray, const HitRec& hit, const PathRec& path, uint32_t sample,
+                          const float* n0, const float* n1, const float* n2, Vec ng, unsigned m, RayRec& nextRay, PathRec& nextPath) {
     const uint32_t pixel = path.pixelDepth & 0xFFFFFFu, depth = path.pixelDepth >> 24;
-    if (depth >= maxDepth || hit.triangle >= sc.triangleCount) return false;                 // :113-114
-    const uint32_t* tri = sc.indices + size_t(hit.triangle) * 3;
     const float u = hit.u, v = hit.v, w = 1.0f - u - v;                                       // :218-227: w,u,v weight index 0,1,2
-    const float* n0 = sc.normals + size_t(tri[0]) * 4;
-    const float* n1 = sc.normals + size_t(tri[1]) * 4;
-    const float* n2 = sc.normals + size_t(tri[2]) * 4;
     Vec n = normalize(Vec{n0[0] * w + n1[0] * u + n2[0] * v, n0[1] * w + n1[1] * u + n2[1] * v, n0[2] * w + n1[2] * u + n2[2] * v});
-    const float* a = sc.vertices + size_t(tri[0]) * 4;
-    const float* b = sc.vertices + size_t(tri[1]) * 4;
-    const float* c = sc.vertices + size_t(tri[2]) * 4;
-    Vec ng = normalize(cross(Vec{b[0] - a[0], b[1] - a[1], b[2] - a[2]}, Vec{c[0] - a[0], c[1] - a[1], c[2] - a[2]}));
     const Vec d{ray.dir[0], ray.dir[1], ray.dir[2]};
     const Vec wo = d * -1.0f;
     if (dot(ng, wo) < 0.0f) ng = ng * -1.0f;        // geometric normal toward the viewer side
     if (dot(n, wo) < 0.0f) n = n * -1.0f;
     Vec wi;
     float colour[3];
-    const unsigned m = sc.triangleMaterials[hit.triangle] & 3u;
     const uint32_t key = pathKey(pixel, sample);
     if (!sampleMaterial(mat, m, n, wo, uniformKeyed(key, depth + 1, 3), uniformKeyed(key, depth + 1, 4), uniformKeyed(key, depth + 1, 5), wi, colour)) return false;
     const float wgt[3] = {path.weight[0] * colour[0], path.weight[1] * colour[1], path.weight[2] * colour[2]};
@@ -181,6 +177,32 @@ RACC_HD bool shadeHit(const SceneView& sc, const Materials& mat, uint32_t maxDep
     nextPath.weight[0] = wgt[0]; nextPath.weight[1] = wgt[1]; nextPath.weight[2] = wgt[2];
     nextPath.pixelDepth = pixel | ((depth + 1) << 24);                                          // :414
     return true;
+}
+
+// The same, gathering the triangle's data from the scene arrays (what the host consumer does per hit).
+RACC_HD bool shadeHit(const SceneView& sc, const Materials& mat, uint32_t maxDepth, const RayRec& ray, const HitRec& hit,
+                      const PathRec& path, uint32_t sample, RayRec& nextRay, PathRec& nextPath) {
+    if ((path.pixelDepth >> 24) >= maxDepth || hit.triangle >= sc.triangleCount) return false;   // :113-114
+    const uint32_t* tri = sc.indices + size_t(hit.triangle) * 3;
+    const Vec ng = geometricNormal(sc.vertices + size_t(tri[0]) * 4, sc.vertices + size_t(tri[1]) * 4, sc.vertices + size_t(tri[2]) * 4);
+    return shadeSurface(mat, ray, hit, path, sample, sc.normals + size_t(tri[0]) * 4, sc.normals + size_t(tri[1]) * 4,
+                        sc.normals + size_t(tri[2]) * 4, ng, sc.triangleMaterials[hit.triangle] & 3u, nextRay, nextPath);
+}
+
+// Per-triangle shading record of the device consumer: everything shadeSurface needs in ONE aligned 64 B gather instead
+// of 3 indices + 3 normals + 3 vertices in seven different cache lines.  Built on the host with the functions above, so
+// the values are the ones the host consumer computes per hit.
+struct alignas(64) ShadeTri { float n0[3], n1[3], n2[3], ng[3]; uint32_t material; uint32_t pad[3]; };
+
+inline void buildShadeTri(const SceneView& sc, uint32_t triangle, ShadeTri& out) {
+    const uint32_t* tri = sc.indices + size_t(triangle) * 3;
+    for (int k = 0; k < 3; ++k) {
+        out.n0[k] = sc.normals[size_t(tri[0]) * 4 + k]; out.n1[k] = sc.normals[size_t(tri[1]) * 4 + k]; out.n2[k] = sc.normals[size_t(tri[2]) * 4 + k];
+    }
+    const Vec ng = geometricNormal(sc.vertices + size_t(tri[0]) * 4, sc.vertices + size_t(tri[1]) * 4, sc.vertices + size_t(tri[2]) * 4);
+    out.ng[0] = ng.x; out.ng[1] = ng.y; out.ng[2] = ng.z;
+    out.material = sc.triangleMaterials[triangle] & 3u;
+    out.pad[0] = out.pad[1] = out.pad[2] = 0;
 }
 
 }  // namespace ptshade
