@@ -436,7 +436,13 @@ __global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) 
     uint32_t rayIdx = 0;
     uint32_t node = kEmpty;     // bit31: inner ref | >= kLeafBase: leaf, pairs pending | kDone: awaiting epilogue | kEmpty
     uint32_t sp = 0, top = 0;   // stack height; register copy of entry sp-1
-    uint32_t wBeg = 0, wEnd = 0;
+    // A wave's first chunk is static — its own index in the grid — and the shared cursor hands out everything after those:
+    // 5,120 waves hitting one address at launch queue up behind each other (same-address atomics retire at about one per
+    // 10 ns on this part, i.e. 50 us until the last wave had work).
+    // (readfirstlane: the wave index is uniform, but only this tells the compiler — otherwise wBeg/wEnd/exhausted and the
+    // whole loop control turn into exec-masked vector code: measured +7 % per ray)
+    uint32_t wBeg = XQ ? 0u : min((blockIdx.x * uint32_t(BLOCK / 64) + uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6)))) * a.chunk, a.count);
+    uint32_t wEnd = XQ ? 0u : min(wBeg + a.chunk, a.count);
     bool exhausted = false;
     uint32_t xqTried = 0;       // XQ: how many of the 8 per-XCD queues this wave has found empty
     uint32_t stInner = 0, stInnerLanes = 0, stLeaf = 0, stLeafLanes = 0, stRefill = 0, stLoaded = 0, stDeq = 0;
@@ -513,9 +519,12 @@ __global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) 
             if (wBeg == wEnd && !exhausted) {
                 if (STATS) ++stDeq;
                 if (!XQ) {
+                    // (a wave's FIRST chunk is static, see the initialisation of wBeg/wEnd: the cursor hands out the rest)
                     uint32_t b = 0;
                     if (lane == 0) b = atomicAdd(a.cursor, a.chunk);
-                    b = __builtin_amdgcn_readfirstlane(b);
+                    const uint32_t r = __builtin_amdgcn_readfirstlane(b);
+                    b = r + gridDim.x * uint32_t(BLOCK / 64) * a.chunk;
+                    if (b < r) b = 0xFFFFFFFFu;      // 32-bit wrap: past any batch
                     wBeg = min(b, a.count);
                     wEnd = min(b + a.chunk, a.count);
                     exhausted = (b >= a.count) || (b + a.chunk < b);
