@@ -525,9 +525,9 @@ __global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) 
                     const uint32_t r = __builtin_amdgcn_readfirstlane(b);
                     b = r + gridDim.x * uint32_t(BLOCK / 64) * a.chunk;
                     if (b < r) b = 0xFFFFFFFFu;      // 32-bit wrap: past any batch
-                    wBeg = min(b, a.count);
-                    wEnd = min(b + a.chunk, a.count);
                     exhausted = (b >= a.count) || (b + a.chunk < b);
+                    wBeg = exhausted ? a.count : b;
+                    wEnd = exhausted ? a.count : min(b + a.chunk, a.count);
                 } else {
                     // XCD-partitioned queue: workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own L2.
                     // The batch is cut into 8 contiguous eighths with a cursor each; a wave drains its own XCD's eighth first
