@@ -49,10 +49,12 @@ typedef struct racc_hip_options {
     uint32_t refill_min;       /* idle lanes that trigger a wave refill; 0 => default */
     uint32_t leaf_min;         /* leaf-holding lanes that trigger a leaf step; 0 => default */
     uint32_t chunk;            /* rays a wave dequeues per cursor atomic; 0 => default */
-    uint32_t tail_active;      /* waves with <= this many live rays run both step bodies per iteration;
-                                  0 => default (16), > 64 => never */
+    uint32_t tail_active;      /* waves with <= this many live rays ("thin") run both step bodies per iteration;
+                                  0 => default (32), > 64 => never */
     uint32_t regroup_period;   /* V3 kernels: scheduling iterations between workgroup-wide regroupings; 0 => default */
-    uint32_t reserved[7];
+    uint32_t thin_reps;        /* V2 kernels: inner steps a thin wave runs per scheduling iteration; 0 => default (8) */
+    uint32_t inner_reps;       /* V2 kernels: inner steps any other wave runs per scheduling iteration; 0 => default (3) */
+    uint32_t reserved[5];
 } racc_hip_options;
 
 typedef struct racc_hip_scene_info {

@@ -41,7 +41,7 @@ class RaccError(RuntimeError):
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("lanes", C.c_uint32), ("waves_per_simd", C.c_uint32),
                 ("kernel_variant", C.c_uint32), ("refill_min", C.c_uint32), ("leaf_min", C.c_uint32),
-                ("chunk", C.c_uint32), ("tail_active", C.c_uint32), ("regroup_period", C.c_uint32), ("reserved", C.c_uint32 * 7)]
+                ("chunk", C.c_uint32), ("tail_active", C.c_uint32), ("regroup_period", C.c_uint32), ("thin_reps", C.c_uint32), ("inner_reps", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 
 class SceneInfo(C.Structure):
@@ -236,12 +236,13 @@ class DeviceBuffer:
 class Context:
     """≙ racc::Context for the GPU intersect path; one per (process, GPU)."""
 
-    def __init__(self, device=0, lanes=0, waves_per_simd=0, refill_min=0, leaf_min=0, chunk=0, kernel_variant=0, tail_active=0, regroup_period=0):
+    def __init__(self, device=0, lanes=0, waves_per_simd=0, refill_min=0, leaf_min=0, chunk=0, kernel_variant=0, tail_active=0, regroup_period=0, thin_reps=0, inner_reps=0):
         lib = load_library()
         o = Options()
         o.struct_size = C.sizeof(Options)
         o.lanes, o.waves_per_simd, o.refill_min, o.leaf_min, o.chunk, o.kernel_variant = lanes, waves_per_simd, refill_min, leaf_min, chunk, kernel_variant
-        o.tail_active, o.regroup_period = tail_active, regroup_period
+        o.tail_active, o.regroup_period, o.thin_reps = tail_active, regroup_period, thin_reps
+        o.inner_reps = inner_reps
         h = C.c_void_p()
         _check(lib.racc_hip_create(device, C.byref(o), C.byref(h)))
         self._h = h
