@@ -1170,7 +1170,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     if (vp->noSpill && scene->info.inner_height > uint32_t(vp->stackLevels())) vp = &kVariants[kSpillFallback - 1];   // tall tree
     const Variant& v = *vp;
     const uint32_t ldsBytes = uint32_t(v.cacheNodes) * 64u + uint32_t(v.ldsLevels) * uint32_t(v.block) * 4u + (v.ldsLevels > 32 ? 272u : 0u);
-    const uint32_t wavesPerSimd = optOr(ctx->opts.waves_per_simd, 5u);   // measured best on 1M-ray batches (profiles/)
+    const uint32_t wavesPerSimd = optOr(ctx->opts.waves_per_simd, 6u);   // measured best on 1M-ray batches (5: +1.3 %, 4: +8 % per ray); LDS caps it below
     const uint32_t wavesPerBlock = uint32_t(v.block) / 64u;
     uint32_t blocksPerCU = (wavesPerSimd * 4u) / wavesPerBlock;
     if (blocksPerCU < 1u) blocksPerCU = 1u;
