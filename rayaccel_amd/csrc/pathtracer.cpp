@@ -118,6 +118,15 @@ struct Renderer {
 
 }  // namespace
 
+// Test hooks into pt_shade.h (host build; the device build of the same header is checked against this one through the
+// rendered images): n values of sin/cos(2*pi*r), and n uniforms of the counter RNG.
+extern "C" void racc_pt_test_sincos2pi(const float* r, uint32_t n, float* s, float* c) {
+    for (uint32_t i = 0; i < n; ++i) ptshade::sincos2pi(r[i], s[i], c[i]);
+}
+extern "C" void racc_pt_test_uniform(uint32_t pixel, uint32_t sample, uint32_t depth, uint32_t stream, uint32_t n, float* out) {
+    for (uint32_t i = 0; i < n; ++i) out[i] = ptshade::uniformKeyed(ptshade::pathKey(pixel + i, sample), depth, stream);
+}
+
 extern "C" int racc_pt_render_file(const char* scene_bin, int device, uint32_t width, uint32_t height,
                                    uint32_t spp_first, uint32_t spp_count, uint32_t max_depth,
                                    uint32_t cpu_threads, double* rgb_sum, racc_pt_stats* stats) {

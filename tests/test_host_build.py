@@ -70,3 +70,28 @@ def test_error_behaviour():
     assert lib.racc_host_scene_build(C.c_void_p(addr), 8, vp(np.arange(9, dtype=np.uint32) % 8), 9, C.byref(h)) == -1   # Scene.cpp:187
     with pytest.raises(ra.RaccError):
         ra.HostScene(v, idx[:3])
+
+
+def test_path_tracer_shared_arithmetic():
+    """pt_shade.h (compiled verbatim by the host and the device consumer): the polynomial sin/cos that replaces the two
+    math libraries stays within 2e-7 of the true value on [0, 1), is exact at the quadrant boundaries, and the counter RNG
+    produces 24-bit uniforms in [0, 1) with a flat histogram."""
+    import ctypes as C
+    from rayaccel_amd import engine
+    engine.load_library()
+    lib = C.CDLL(engine.PT_LIB_PATH)
+    r = np.concatenate([np.arange(0, 1 << 16, dtype=np.float32) / np.float32(1 << 16),
+                        np.random.default_rng(5).random(200000, dtype=np.float32),
+                        np.array([0.0, 0.25, 0.5, 0.75, np.nextafter(np.float32(1), np.float32(0))], np.float32)])
+    s, c = np.zeros_like(r), np.zeros_like(r)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.racc_pt_test_sincos2pi(vp(r), C.c_uint32(len(r)), vp(s), vp(c))
+    ang = 2.0 * np.pi * r.astype(np.float64)
+    assert np.abs(s - np.sin(ang)).max() < 2e-7 and np.abs(c - np.cos(ang)).max() < 2e-7
+    assert np.abs(s.astype(np.float64) ** 2 + c.astype(np.float64) ** 2 - 1).max() < 5e-7
+    assert (s[-5], c[-5]) == (0.0, 1.0) and (s[-4], c[-4]) == (1.0, 0.0) and (s[-3], c[-3]) == (0.0, -1.0) and (s[-2], c[-2]) == (-1.0, 0.0)
+    u = np.zeros(1 << 18, np.float32)
+    lib.racc_pt_test_uniform(C.c_uint32(12345), C.c_uint32(7), C.c_uint32(2), C.c_uint32(3), C.c_uint32(len(u)), vp(u))
+    assert u.min() >= 0.0 and u.max() < 1.0 and np.all(u * (1 << 24) == np.floor(u * (1 << 24)))
+    hist = np.bincount((u * 64).astype(int), minlength=64)
+    assert hist.min() > 0.9 * len(u) / 64 and hist.max() < 1.1 * len(u) / 64 and abs(u.mean() - 0.5) < 2e-3
