@@ -14,11 +14,13 @@
 //     — unlike the reference's unchecked stack[64] it cannot overflow;
 //   * hit epilogues (remap gather + barycentric rotation) are batched into the refill step; miss radiance is evaluated by
 //     a second, streaming kernel (envShadeKernel).
-// Three generations live in this file and are selectable through racc_hip_options::kernel_variant:
+// Four generations live in this file and are selectable through racc_hip_options::kernel_variant:
 //   traverseKernel    V1, the first correct kernel, also with an optional LDS cache of the top of the tree;
-//   traverseKernelV2  the shipped one: V1 + thin-wave (drain) policy, lazy epilogues, deferred miss shading;
+//   traverseKernelV2  the shipped one: V1 + thin-wave (drain) policy, lazy epilogues, deferred miss shading, static first
+//                     chunk, while-while inner repeats;
 //   traverseKernelV3  experiment: workgroup-wide regrouping of rays by phase through LDS (higher lane utilisation,
-//                     lost to its barriers).
+//                     lost to its barriers);
+//   traverseKernelV4  experiment: two rays per lane (86 % lane utilisation, paid back in selects and registers).
 // Arithmetic is IEEE binary32 with explicit fmaf only (built with -ffp-contract=off, no fast-math), the same evaluation
 // order as oracle/racc_oracle.c, so primId/t/u/v are bit-identical to the CPU restatement for every finite ray.  The
 // traversal ORDER is the reference's (nearer child first, far child pushed only if both hit, pairs of a leaf in order),
@@ -695,6 +697,228 @@ __global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) 
     }
 }
 
+// ================================================================================================ V4
+// Two rays per lane.  The VALU is the bound (SQ_INSTS_VALU x 4 cycles fill ~80 % of the SIMD cycles in steady state) and
+// a third of the lanes idle in every inner step: they sit at a leaf waiting for the vote, or wait for the next refill.
+// Here every lane owns TWO ray slots (A, B), each with its own stack column, and takes part in a step if EITHER slot holds
+// the right kind of work; the state of the chosen slot is selected into the step's operands with v_cndmask (~16 extra
+// VALU per inner step, ~25 per leaf step).  The CPU model (oracle/wave_sim.c) predicts 64.8 + 9.1 scheduling iterations
+// per 64 rays instead of 80.5 + 16.2.  A ray's own sequence of steps is untouched: results stay bit-identical.
+//   LDS: [level][slot][thread]; the traversal stack rarely exceeds 8 entries (0.007 % of the rays pass 12 on the bench
+//   batch), so each slot keeps LDS_LEVELS = 13 levels in LDS (26 KiB per workgroup, as V2) and spills above that.
+struct RaySlot {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz, ex, ey, ez, tNear, tFar;
+    int hitIndex;
+    float hitU, hitV;
+    uint32_t rayIdx, node, sp;
+};
+
+template <int BLOCK, int LDS_LEVELS, bool STATS>
+__global__ void __launch_bounds__(BLOCK) traverseKernelV4(const TraverseArgs a) {
+    __shared__ uint32_t lds[2 * LDS_LEVELS * BLOCK];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t gtid = blockIdx.x * BLOCK + tid;
+
+    RaySlot A, B;
+#define RACC4_CLEAR(S) do { S.ox = S.oy = S.oz = S.dx = S.dy = S.dz = S.ix = S.iy = S.iz = S.ex = S.ey = S.ez = 0.0f; \
+                            S.tNear = S.tFar = 0.0f; S.hitIndex = -1; S.hitU = S.hitV = 0.0f; S.rayIdx = 0; S.node = kEmpty; S.sp = 0; } while (0)
+    RACC4_CLEAR(A); RACC4_CLEAR(B);
+    uint32_t wBeg = min((blockIdx.x * uint32_t(BLOCK / 64) + uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6)))) * a.chunk, a.count);
+    uint32_t wEnd = min(wBeg + a.chunk, a.count);
+    bool exhausted = false;
+    uint32_t stInner = 0, stInnerLanes = 0, stLeaf = 0, stLeafLanes = 0, stRefill = 0, stLoaded = 0, stDeq = 0;
+    unsigned long long cyStart = 0;
+    if (STATS) cyStart = __builtin_readcyclecounter();
+
+    // stack entry (level, slot) of this thread
+#define RACC4_LDS(level, slot) lds[((level) * 2u + (slot)) * BLOCK + tid]
+#define RACC4_SPILL(level, slot) a.spill[size_t(((level) - LDS_LEVELS) * 2u + (slot)) * a.spillStride + gtid]
+
+    for (uint32_t iter = 0;; ++iter) {
+        if (iter >= a.maxIters) {
+            if (lane == 0) atomicAdd(a.cursor + 2, 1u);
+            break;
+        }
+        const bool innerA = int(A.node) < 0, innerB = int(B.node) < 0;
+        const bool leafA = int(A.node) >= int(kLeafBase), leafB = int(B.node) >= int(kLeafBase);
+        const uint32_t nInner = __popcll(__ballot(innerA || innerB));       // lanes that can take an inner step
+        const uint32_t nLeaf = __popcll(__ballot(leafA || leafB));
+        const uint32_t idleSlots = uint32_t(__popcll(__ballot(A.node <= kDone))) + uint32_t(__popcll(__ballot(B.node <= kDone)));
+        const bool noWork = (nInner | nLeaf) == 0u;
+        bool refill = noWork;
+        if (!noWork) {
+            if (!exhausted) refill = idleSlots >= a.refillMin;
+            else refill = uint32_t(__popcll(__ballot(A.node == kDone))) + uint32_t(__popcll(__ballot(B.node == kDone))) >= a.refillMin;
+        }
+
+        if (refill) {
+            if (STATS) ++stRefill;
+            // ---------------- batched epilogue (Kernels.h:213-241), slot by slot ----------------
+#define RACC4_EPILOGUE(S)                                                                                              \
+            if (S.node == kDone) {                                                                                     \
+                float4 out;                                                                                            \
+                if (S.hitIndex < 0) {                                                                                  \
+                    out = a.env ? make_float4(__uint_as_float(kInvalidTriangle), S.dx, S.dy, S.dz)                     \
+                                : make_float4(__uint_as_float(kInvalidTriangle), 0.0f, 0.0f, 0.0f);                    \
+                } else {                                                                                               \
+                    uint32_t m = a.remap[S.hitIndex];                                                                  \
+                    const uint32_t edge = m >> 30;                                                                     \
+                    m &= 0x3FFFFFFFu;                                                                                  \
+                    const float bx = S.hitU, by = S.hitV, bz = 1.0f - S.hitU - S.hitV;                                 \
+                    float u = bx, v = by;                                                                              \
+                    if (edge == 1u) { u = bz; v = bx; } else if (edge == 2u) { u = by; v = bz; }                       \
+                    out = make_float4(__uint_as_float(m), S.tFar, u, v);                                               \
+                }                                                                                                      \
+                a.results[S.rayIdx] = out;                                                                             \
+                S.node = kEmpty;                                                                                       \
+            }
+            RACC4_EPILOGUE(A)
+            RACC4_EPILOGUE(B)
+            // ---------------- refill: empty A slots first, then empty B slots ----------------
+            const uint64_t emptyA = __ballot(A.node == kEmpty), emptyB = __ballot(B.node == kEmpty);
+            const uint32_t needA = __popcll(emptyA), need = needA + uint32_t(__popcll(emptyB));
+            if (wBeg == wEnd && !exhausted) {
+                if (STATS) ++stDeq;
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(a.cursor, a.chunk);
+                const uint32_t r = __builtin_amdgcn_readfirstlane(b);
+                b = r + gridDim.x * uint32_t(BLOCK / 64) * a.chunk;
+                if (b < r) b = 0xFFFFFFFFu;
+                exhausted = (b >= a.count) || (b + a.chunk < b);
+                wBeg = exhausted ? a.count : b;
+                wEnd = exhausted ? a.count : min(b + a.chunk, a.count);
+            }
+            const uint32_t take = min(need, wEnd - wBeg);
+            const uint32_t rankA = laneRank(emptyA), rankB = needA + laneRank(emptyB);
+#define RACC4_LOAD(S, rank)                                                                                            \
+            if (S.node == kEmpty && (rank) < take) {                                                                   \
+                const uint32_t idx = wBeg + (rank);                                                                    \
+                const float4 q0 = a.rays[size_t(idx) * 2 + 0];                                                         \
+                const float4 q1 = a.rays[size_t(idx) * 2 + 1];                                                         \
+                const bool valid = isfinite(q0.x) && isfinite(q0.y) && isfinite(q0.z) && isfinite(q0.w) &&             \
+                                   isfinite(q1.x) && isfinite(q1.y) && isfinite(q1.z) && !isnan(q1.w);                 \
+                if (!valid) {                                                                                          \
+                    a.results[idx] = make_float4(__uint_as_float(kInvalidTriangle), a.env ? __uint_as_float(0x7FC00000u) : 0.0f, 0.0f, 0.0f); \
+                } else {                                                                                               \
+                    const float eps = 1e-10f;                                                                          \
+                    S.ox = q0.x; S.oy = q0.y; S.oz = q0.z; S.tNear = q0.w;                                             \
+                    S.dx = (fabsf(q1.x) < eps) ? copysignf(eps, q1.x) : q1.x;                                          \
+                    S.dy = (fabsf(q1.y) < eps) ? copysignf(eps, q1.y) : q1.y;                                          \
+                    S.dz = (fabsf(q1.z) < eps) ? copysignf(eps, q1.z) : q1.z;                                          \
+                    S.tFar = q1.w;                                                                                     \
+                    S.ix = 1.0f / S.dx; S.iy = 1.0f / S.dy; S.iz = 1.0f / S.dz;                                        \
+                    S.ex = -S.ox * S.ix; S.ey = -S.oy * S.iy; S.ez = -S.oz * S.iz;                                     \
+                    S.hitIndex = -1; S.hitU = 0.0f; S.hitV = 0.0f;                                                     \
+                    S.rayIdx = idx;                                                                                    \
+                    S.node = 0x80000000u;                                                                              \
+                    S.sp = 0;                                                                                          \
+                }                                                                                                      \
+            }
+            RACC4_LOAD(A, rankA)
+            RACC4_LOAD(B, rankB)
+            wBeg += take;
+            if (STATS) stLoaded += take;
+            if (exhausted && wBeg == wEnd && __ballot(A.node != kEmpty || B.node != kEmpty) == 0ull) break;
+            continue;
+        }
+
+        const uint32_t nActive = __popcll(__ballot(innerA || innerB || leafA || leafB));
+        const bool doLeaf = nLeaf >= a.leafMin || nInner == 0u || nLeaf * 4u >= nActive;
+        const bool doInner = nInner != 0u && (!doLeaf || nActive <= a.tailActive);
+        if (doLeaf) {
+            // ---------------- leaf step on slot A if it waits at a leaf, else on slot B ----------------
+            if (STATS) { ++stLeaf; stLeafLanes += nLeaf; }
+            const bool la = int(A.node) >= int(kLeafBase), lb = int(B.node) >= int(kLeafBase);
+            if (la || lb) {
+                const bool useB = !la;
+                const uint32_t node = useB ? B.node : A.node;
+                LaneRay r;
+                r.ox = useB ? B.ox : A.ox; r.oy = useB ? B.oy : A.oy; r.oz = useB ? B.oz : A.oz;
+                r.dx = useB ? B.dx : A.dx; r.dy = useB ? B.dy : A.dy; r.dz = useB ? B.dz : A.dz;
+                r.ix = r.iy = r.iz = r.ex = r.ey = r.ez = 0.0f;      // unused by the pair test
+                r.tNear = useB ? B.tNear : A.tNear; r.tFar = useB ? B.tFar : A.tFar;
+                r.hitIndex = useB ? B.hitIndex : A.hitIndex; r.hitU = useB ? B.hitU : A.hitU; r.hitV = useB ? B.hitV : A.hitV;
+                const uint32_t cur = node & 0xFFFFFFu;
+                const uint32_t cnt = node >> 24;
+                const float4 t0 = a.pairs[cur * 3u], t1 = a.pairs[cur * 3u + 1u], t2 = a.pairs[cur * 3u + 2u];
+                r.tFar = pairIntersectData(t0, t1, t2, cur, r);
+                uint32_t sp = useB ? B.sp : A.sp;
+                uint32_t next;
+                if (cnt > 1u) next = ((cnt - 1u) << 24) | (cur + 1u);
+                else if (sp == 0u) next = kDone;
+                else {
+                    --sp;
+                    next = RACC4_LDS(min(sp, uint32_t(LDS_LEVELS - 1)), useB ? 1u : 0u);
+                    if (sp >= uint32_t(LDS_LEVELS)) next = RACC4_SPILL(sp, useB ? 1u : 0u);
+                }
+                if (useB) { B.tFar = r.tFar; B.hitIndex = r.hitIndex; B.hitU = r.hitU; B.hitV = r.hitV; B.node = next; B.sp = sp; }
+                else      { A.tFar = r.tFar; A.hitIndex = r.hitIndex; A.hitU = r.hitU; A.hitV = r.hitV; A.node = next; A.sp = sp; }
+            }
+        }
+        if (doInner) {
+            // ---------------- inner steps on slot A if it holds an inner node, else on slot B ----------------
+            const uint32_t reps = nActive <= a.tailActive ? a.thinReps : a.innerReps;
+            for (uint32_t rep = 0;; ++rep) {
+                const bool ia = int(A.node) < 0, ib = int(B.node) < 0;
+                if (STATS) { ++stInner; stInnerLanes += uint32_t(__popcll(__ballot(ia || ib))); }
+                if (ia || ib) {
+                    const bool useB = !ia;
+                    const uint32_t node = useB ? B.node : A.node;
+                    const float4* np = a.nodes + size_t(node & 0x7FFFFFFFu) * 4;
+                    const uint2 kids = *reinterpret_cast<const uint2*>(np);
+                    const float4 d1 = np[1], d2 = np[2], d3 = np[3];
+                    asm volatile("" :: "v"(kids.x), "v"(kids.y));
+                    const float ix = useB ? B.ix : A.ix, iy = useB ? B.iy : A.iy, iz = useB ? B.iz : A.iz;
+                    const float ex = useB ? B.ex : A.ex, ey = useB ? B.ey : A.ey, ez = useB ? B.ez : A.ez;
+                    const float tNear = useB ? B.tNear : A.tNear, tRay = useB ? B.tFar : A.tFar;
+                    uint32_t sp = useB ? B.sp : A.sp;
+                    float tFirst, tLast;
+                    slabPair(d1, d2, d3, ix, iy, iz, ex, ey, ez, tNear, tRay, tFirst, tLast);
+                    const float firstDiff = tRay - tFirst, lastDiff = tRay - tLast;
+                    uint32_t next;
+                    if (firstDiff + lastDiff != 0.0f) {
+                        const bool lastNearer = tLast < tFirst;
+                        if (tFirst != tRay && tLast != tRay) {
+                            const uint32_t far = lastNearer ? kids.x : kids.y;
+                            if (sp < uint32_t(LDS_LEVELS)) RACC4_LDS(sp, useB ? 1u : 0u) = far;
+                            else RACC4_SPILL(sp, useB ? 1u : 0u) = far;
+                            ++sp;
+                        }
+                        next = lastNearer ? kids.y : kids.x;
+                    } else if (sp == 0u) {
+                        next = kDone;
+                    } else {
+                        --sp;
+                        next = RACC4_LDS(min(sp, uint32_t(LDS_LEVELS - 1)), useB ? 1u : 0u);
+                        if (sp >= uint32_t(LDS_LEVELS)) next = RACC4_SPILL(sp, useB ? 1u : 0u);
+                    }
+                    if (useB) { B.node = next; B.sp = sp; } else { A.node = next; A.sp = sp; }
+                }
+                if (rep + 1u >= reps || __ballot(int(A.node) < 0 || int(B.node) < 0) == 0ull) break;
+            }
+        }
+    }
+#undef RACC4_CLEAR
+#undef RACC4_LDS
+#undef RACC4_SPILL
+#undef RACC4_EPILOGUE
+#undef RACC4_LOAD
+
+    if (STATS && lane == 0) {
+        atomicAdd(a.stats + 0, (unsigned long long)stInner); atomicAdd(a.stats + 1, (unsigned long long)stInnerLanes);
+        atomicAdd(a.stats + 2, (unsigned long long)stLeaf);  atomicAdd(a.stats + 3, (unsigned long long)stLeafLanes);
+        atomicAdd(a.stats + 4, (unsigned long long)stRefill); atomicAdd(a.stats + 5, (unsigned long long)stLoaded);
+        atomicAdd(a.stats + 6, (unsigned long long)stDeq);   atomicAdd(a.stats + 7, 1ull);
+        atomicAdd(a.stats + 13, (unsigned long long)(__builtin_readcyclecounter() - cyStart));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t prev = atomicInc(a.cursor + 1, gridDim.x - 1);
+        if (prev == gridDim.x - 1) atomicExch(a.cursor, 0u);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 
 // ================================================================================================ V3
@@ -1114,7 +1338,8 @@ struct Variant {
     void (*kernel)(const TraverseArgs);
     bool noSpill = false;      // kernel has no global spill path: only valid while tree height <= ldsLevels
     bool deferEnv = false;     // kernel parks miss directions; envShadeKernel must follow
-    int stackLevels() const { return ldsLevels > 32 ? ldsLevels - (kRecFields + 1) : ldsLevels; }   // V3 rows fold the record words into ldsLevels
+    int slots = 1;             // ray slots per lane (V4: 2); ldsLevels counts all of them
+    int stackLevels() const { return ldsLevels > 32 ? ldsLevels - (kRecFields + 1) : ldsLevels / slots; }   // V3 rows fold the record words into ldsLevels
 };
 // kernel_variant n selects kVariants[n-1]; 0 selects kDefaultVariant.  LDS per workgroup = cacheNodes*64 + ldsLevels*block*4.
 const Variant kVariants[] = {
@@ -1146,6 +1371,8 @@ const Variant kVariants[] = {
     {256, 26, 0, traverseKernelV2<256, 26, false, true, false, false, false>, true, true}, // 26: variant 22 + statistics (debug)
     {256, 26, 0, traverseKernelV2<256, 26, false, false, false, false, false, true>, true, true}, // 27: variant 22 with the node records transposed to SoA planes (ablation: DESIGN.md §2)
     {256, 26, 0, traverseKernelV2<256, 26, false, false, false, false, false, false, true>, true, true}, // 28: variant 22 + touch loads of both children in thin waves
+    {256, 26, 0, traverseKernelV4<256, 13, false>, false, true, 2},   // 29: V4, two ray slots per lane, 13 LDS levels each + spill
+    {256, 26, 0, traverseKernelV4<256, 13, true>, false, true, 2},    // 30: variant 29 + statistics (debug)
 };
 constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kSoaVariant = 27;
@@ -1179,7 +1406,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     const uint32_t blocksNeeded = (count + uint32_t(v.block) - 1) / uint32_t(v.block);
     if (blocks > blocksNeeded) blocks = blocksNeeded;
     const uint32_t gridThreads = blocks * uint32_t(v.block);
-    const uint32_t spillLevels = scene->info.inner_height > uint32_t(v.stackLevels()) ? scene->info.inner_height - uint32_t(v.stackLevels()) : 0u;
+    const uint32_t spillLevels = (scene->info.inner_height > uint32_t(v.stackLevels()) ? scene->info.inner_height - uint32_t(v.stackLevels()) : 0u) * uint32_t(v.slots);
     if (int rc = ensureSpill(ctx, lane, uint32_t(ctx->numCUs) * 2048u, spillLevels)) return rc;
 
     TraverseArgs a;
@@ -1197,7 +1424,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.cursor = lane.cursor;
     a.spill = lane.spill;
     a.spillStride = gridThreads;
-    a.chunk = optOr(ctx->opts.chunk, 64u);
+    a.chunk = optOr(ctx->opts.chunk, 64u * uint32_t(v.slots));
     a.refillMin = optOr(ctx->opts.refill_min, 32u);
     a.leafMin = optOr(ctx->opts.leaf_min, 12u);
     a.maxIters = 1u << 24;
