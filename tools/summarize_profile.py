@@ -10,10 +10,10 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join("gpurun_out", "prof_" + tag)
 dst = os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)   # newest run if several were merged
 if stats:
-    shutil.copy(stats[0], os.path.join(dst, "kernel_stats.csv"))
-trace = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))
+    shutil.copy(stats[-1], os.path.join(dst, "kernel_stats.csv"))
+trace = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv")), key=os.path.getmtime)[-1:]
 out = {}
 if trace:
     rows = [r for r in csv.DictReader(open(trace[0])) if "traverseKernel" in r["Kernel_Name"]]
@@ -22,7 +22,12 @@ if trace:
     out["kernel_trace"] = dict(kernel=rows[0]["Kernel_Name"], timed_diffuse_mean_ms=float(np.mean(dur[4:24])), timed_diffuse_min_ms=float(np.min(dur[4:24])),
                                vgpr=rows[0].get("VGPR_Count"), sgpr=rows[0].get("SGPR_Count"), lds=rows[0].get("LDS_Block_Size"),
                                grid=rows[4].get("Grid_Size"), workgroup=rows[4].get("Workgroup_Size"))
-for d in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
+_newest = {}
+for d in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):   # newest file of every counter set
+    k = d.split(os.sep)[-3]
+    if k not in _newest or os.path.getmtime(d) > os.path.getmtime(_newest[k]):
+        _newest[k] = d
+for d in sorted(_newest.values()):
     byc = collections.defaultdict(list)
     for r in csv.DictReader(open(d)):
         if "traverseKernel" in r["Kernel_Name"]:
