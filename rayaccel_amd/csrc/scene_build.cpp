@@ -7,20 +7,32 @@
 //   inner-node flatten         ≙                   RayAccelerator/Scene.cpp:275-332
 //   pair padding               ≙                   RayAccelerator/Scene.cpp:334-338
 // Design differences from the reference (none change the tree it would build
-// single-threaded): iterative work stack instead of task-parallel recursion, so
-// node numbering is deterministic; one surface-area expression everywhere
-// (fma(dx,dy,fma(dx,dz,dy*dz)), Bvh2.cpp:339); exact 1/area instead of rcpss.
+// single-threaded): subtrees are built by a pool of threads as in the reference
+// (Bvh2.cpp:511-535), but under provisional node ids; a final pass renumbers the
+// finished tree in the order a single-threaded depth-first build allocates ids, so
+// the output does not depend on thread timing (the reference's does); one
+// surface-area expression everywhere (fma(dx,dy,fma(dx,dz,dy*dz)), Bvh2.cpp:339);
+// exact 1/area instead of rcpss.
 // No GPU code here; this file is plain C++ and is also what racc::createScene uses.
 
 #include "racc_hip.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
+
+#include <sched.h>
 
 namespace {
 
@@ -54,16 +66,14 @@ inline float bits_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f;
 
 class Bvh2Builder {
 public:
-    Bvh2Builder(const float* vertices, const uint32_t* indices, uint32_t triangleCount)
-        : verts_(vertices), idx_(indices), T_(triangleCount) {}
+    Bvh2Builder(const float* vertices, const uint32_t* indices, uint32_t triangleCount, unsigned threads)
+        : verts_(vertices), idx_(indices), T_(triangleCount) { threads_ = threads ? threads : 1; }
 
     void run(std::vector<Bvh2Node>& nodes, std::vector<uint32_t>& triangles) {
-        nodes.assign(size_t(T_) * 2, Bvh2Node{});
-        nodes_ = nodes.data();
         boxes_.resize(T_);
         for (auto& s : sorted_) s.resize(T_);
         scratch_.resize(T_);
-        prefixCost_.resize(T_);
+        for (auto& pc : prefixCost_) pc.resize(T_);
         goesLeft_.resize(T_);
 
         Box8 scene;
@@ -79,32 +89,53 @@ public:
             }
             scene.grow(bx);
         }
+        const auto tA = std::chrono::steady_clock::now();
         sortAxes();
+        const auto tB = std::chrono::steady_clock::now();
 
+        // Build under provisional ids (children get whatever pair of slots the atomic counter hands out) ...
+        std::vector<Bvh2Node> tmp(size_t(T_) * 2 + 1);
+        nodes_ = tmp.data();
         Bvh2Node& root = nodes_[0];
+        root = Bvh2Node{};
         root.kind = 0; root.parent = 0xFFFFFFFFu; root.first = 0; root.last = T_;
         storeBounds(root, scene);
+        splits_.store(0);
+        buildParallel();
+        const auto tC = std::chrono::steady_clock::now();
 
-        splits_ = 0;
-        std::vector<uint32_t> work;
-        work.push_back(0);
+        // ... then renumber: replay the id allocation of a single-threaded depth-first build (a split node's children get
+        // the next two ids when the node is visited, the left subtree is finished before the right one).
+        const uint32_t splits = splits_.load();
+        nodes.assign(size_t(splits) * 2 + 1, Bvh2Node{});
+        nodes[0] = tmp[0];
+        std::vector<std::pair<uint32_t, uint32_t>> work;      // (provisional id, final id)
+        work.emplace_back(0u, 0u);
+        uint32_t next = 0;
         while (!work.empty()) {
-            const uint32_t n = work.back();
+            const uint32_t t = work.back().first, f = work.back().second;
             work.pop_back();
-            if (splitNode(n)) {          // children get ids now; left subtree is finished first
-                work.push_back(nodes_[n].last);
-                work.push_back(nodes_[n].first);
-            }
+            if (!tmp[t].kind) continue;                       // leaf: first/last are a triangle range, nothing to relocate
+            ++next;
+            const uint32_t left = next * 2 - 1, right = next * 2;
+            nodes[left] = tmp[tmp[t].first];  nodes[left].parent = f;
+            nodes[right] = tmp[tmp[t].last];  nodes[right].parent = f;
+            nodes[f].first = left; nodes[f].last = right;
+            work.emplace_back(tmp[t].last, right);
+            work.emplace_back(tmp[t].first, left);
         }
-        nodes.resize(size_t(splits_) * 2 + 1);
         triangles = sorted_[0];
+        if (std::getenv("RACC_PROFILE"))
+            std::fprintf(stderr, "RayAccelerator profile: bvh2 with %u threads: sort %.3f s, sweep/partition %.3f s, renumber %.3f s\n", threads_,
+                         std::chrono::duration<double>(tB - tA).count(), std::chrono::duration<double>(tC - tB).count(),
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - tC).count());
     }
 
 private:
     // Order-preserving float key + stable 4-pass LSD radix (Bvh2.cpp:128-184,743-749).
     void sortAxes() {
-        std::vector<uint64_t> keys(T_), tmp(T_);
-        for (int axis = 0; axis < 3; ++axis) {
+        auto one = [this](int axis) {
+            std::vector<uint64_t> keys(T_), tmp(T_);
             for (uint32_t t = 0; t < T_; ++t) {
                 const float mid = (boxes_[t].v[4 + axis] - boxes_[t].v[axis]) * 0.5f;   // (min+max)/2
                 uint32_t e = float_bits(mid);
@@ -122,7 +153,57 @@ private:
                 std::swap(src, dst);
             }
             for (uint32_t t = 0; t < T_; ++t) sorted_[axis][t] = uint32_t(src[t]);
+        };
+        if (threads_ > 1 && T_ > 4096) {
+            std::thread t1(one, 1), t2(one, 2);
+            one(0);
+            t1.join(); t2.join();
+        } else {
+            for (int axis = 0; axis < 3; ++axis) one(axis);
         }
+    }
+
+    // Task pool (≙ the reference's ThreadPool-driven recursion, Bvh2.cpp:511-535): a node with many triangles is one task
+    // whose children become new tasks; a node below the cutoff is finished depth-first by the thread that took it.
+    void buildParallel() {
+        constexpr uint32_t kCutoff = 8192;
+        std::mutex m;
+        std::condition_variable cv;
+        std::vector<uint32_t> queue;
+        uint32_t running = 0;
+        queue.push_back(0);
+        auto worker = [&]() {
+            std::vector<uint32_t> local;
+            std::unique_lock<std::mutex> lock(m);
+            for (;;) {
+                while (queue.empty() && running != 0) cv.wait(lock);
+                if (queue.empty()) { cv.notify_all(); return; }
+                const uint32_t n = queue.back();
+                queue.pop_back();
+                ++running;
+                lock.unlock();
+                const uint32_t count = nodes_[n].last - nodes_[n].first;
+                uint32_t kids[2]; int nk = 0;
+                if (count > kCutoff) {
+                    if (splitNode(n)) { kids[0] = nodes_[n].first; kids[1] = nodes_[n].last; nk = 2; }
+                } else {
+                    local.assign(1, n);
+                    while (!local.empty()) {
+                        const uint32_t c = local.back();
+                        local.pop_back();
+                        if (splitNode(c)) { local.push_back(nodes_[c].last); local.push_back(nodes_[c].first); }
+                    }
+                }
+                lock.lock();
+                for (int k = 0; k < nk; ++k) queue.push_back(kids[k]);
+                --running;
+                cv.notify_all();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned i = 1; i < threads_; ++i) pool.emplace_back(worker);
+        worker();
+        for (std::thread& t : pool) t.join();
     }
 
     static void storeBounds(Bvh2Node& n, const Box8& b) {
@@ -139,12 +220,12 @@ private:
     // Stable partition of one axis list by goesLeft_ (Bvh2.cpp:217-240).
     void partitionAxis(int axis, uint32_t first, uint32_t last) {
         uint32_t* order = sorted_[axis].data();
-        uint32_t l = first, r = 0;
+        uint32_t l = first, r = first;           // scratch_[first..last) belongs to this node: tasks never share a slice
         for (uint32_t i = first; i < last; ++i) {
             const uint32_t t = order[i];
             if (goesLeft_[t]) order[l++] = t; else scratch_[r++] = t;
         }
-        std::copy(scratch_.begin(), scratch_.begin() + r, order + l);
+        std::copy(scratch_.begin() + first, scratch_.begin() + r, order + l);
     }
 
     // Returns true if the node became an inner node (Bvh2.cpp:257-509).
@@ -168,27 +249,37 @@ private:
 
         if (parentArea > 0.0f) {
             float best = std::numeric_limits<float>::infinity();
-            for (int dim = 0; dim < 3; ++dim) {
+            // One axis of the full sweep: the best pivot on `dim` that beats `bestIn`, or none (Bvh2.cpp:326-445).
+            auto sweep = [&](int dim, float bestIn, float& bestOut, uint32_t& found) {
                 const uint32_t* order = sorted_[dim].data();
-                // prefix sweep: cost of [first..i] on the left; stop once it alone exceeds `best`
+                float* prefix = prefixCost_[dim].data();
+                float bestAxis = bestIn;
+                // prefix sweep: cost of [first..i] on the left; stop once it alone exceeds the best so far
                 Box8 b = boxes_[order[first]];
                 uint32_t i = first;
                 for (; i + 1 < last; ++i) {
                     b.grow(boxes_[order[i]]);
-                    prefixCost_[i] = b.halfArea() * float(int(i - first + 1));
-                    if (prefixCost_[i] > best) break;                   // Bvh2.cpp:346-351
+                    prefix[i] = b.halfArea() * float(int(i - first + 1));
+                    if (prefix[i] > bestAxis) break;                    // Bvh2.cpp:346-351
                 }
                 // suffix sweep from the stop point; pivot p splits [first,p) | [p,last)
-                Box8 s = unionOf(sorted_[dim], i, last);
-                uint32_t found = 0xFFFFFFFFu;
+                Box8 sfx = unionOf(sorted_[dim], i, last);
+                found = 0xFFFFFFFFu;
                 for (uint32_t p = i; p > first; --p) {
-                    s.grow(boxes_[order[p]]);
-                    const float right = s.halfArea() * float(int(last - p));
-                    const float sah = prefixCost_[p - 1] + right;
-                    if (sah < best) { best = sah; found = p; }
-                    if (right > best) break;                            // Bvh2.cpp:418,431-432
+                    sfx.grow(boxes_[order[p]]);
+                    const float right = sfx.halfArea() * float(int(last - p));
+                    const float sah = prefix[p - 1] + right;
+                    if (sah < bestAxis) { bestAxis = sah; found = p; }
+                    if (right > bestAxis) break;                        // Bvh2.cpp:418,431-432
                 }
-                if (found != 0xFFFFFFFFu) { pivot = found; axis = dim; }
+                bestOut = bestAxis;
+            };
+            {
+                for (int dim = 0; dim < 3; ++dim) {
+                    float bo; uint32_t found;
+                    sweep(dim, best, bo, found);
+                    if (found != 0xFFFFFFFFu) { best = bo; pivot = found; axis = dim; }
+                }
             }
             const float cost = 2.0f + 1.0f * (1.0f / parentArea) * best;    // Bvh2.cpp:462-465
             if (cost > float(int(count)) * 1.0f) forceMedian = true;
@@ -207,8 +298,8 @@ private:
         partitionAxis((axis + 1) % 3, first, last);
         partitionAxis((axis + 2) % 3, first, last);
 
-        ++splits_;                                                       // Bvh2.cpp:489-509
-        const uint32_t left = splits_ * 2 - 1, right = splits_ * 2;
+        const uint32_t slot = splits_.fetch_add(1) + 1;                  // Bvh2.cpp:489-509 (provisional ids, see run())
+        const uint32_t left = slot * 2 - 1, right = slot * 2;
         node.kind = uint32_t(axis) + 1; node.first = left; node.last = right;
         Bvh2Node& l = nodes_[left];
         Bvh2Node& r = nodes_[right];
@@ -222,11 +313,12 @@ private:
     const uint32_t* idx_;
     uint32_t T_;
     Bvh2Node* nodes_ = nullptr;
-    uint32_t splits_ = 0;
+    std::atomic<uint32_t> splits_{0};
+    unsigned threads_ = 1;
     std::vector<Box8> boxes_;
     std::vector<uint32_t> sorted_[3];
     std::vector<uint32_t> scratch_;
-    std::vector<float> prefixCost_;
+    std::vector<float> prefixCost_[3];
     std::vector<uint8_t> goesLeft_;
 };
 
@@ -245,6 +337,25 @@ TrianglePair packPair(const float* p0, const float* p1, const float* p2, const f
     return q;
 }
 
+}  // namespace
+
+namespace {
+// Threads for the build: RACC_BUILD_THREADS, else the CPUs this process may use (affinity mask capped by the cgroup quota).
+unsigned buildThreads() {
+    if (const char* e = std::getenv("RACC_BUILD_THREADS")) { const long v = std::atol(e); if (v > 0) return unsigned(v > 256 ? 256 : v); }
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = unsigned(CPU_COUNT(&set));
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long quota = 0, period = 0;
+        if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+            const unsigned q = unsigned((quota + period - 1) / period);
+            if (q && q < n) n = q;
+        }
+        std::fclose(f);
+    }
+    return n ? (n > 64 ? 64 : n) : 1u;
+}
 }  // namespace
 
 struct racc_host_scene {
@@ -352,8 +463,13 @@ int racc_host_scene_build(const float* vertices, uint32_t vertex_count,
     try {
         racc_host_scene* s = new racc_host_scene();
         s->triangleCount = T;
-        Bvh2Builder(vertices, indices, T).run(s->bvh, s->triangles);
+        const bool prof = std::getenv("RACC_PROFILE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        Bvh2Builder(vertices, indices, T, buildThreads()).run(s->bvh, s->triangles);
+        const auto t1 = std::chrono::steady_clock::now();
         const int rc = flatten(*s, vertices, indices);
+        if (prof) std::fprintf(stderr, "RayAccelerator profile: scene build %u triangles: bvh2 %.3f s, pack+flatten %.3f s\n", T,
+                               std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
         if (rc != RACC_HIP_OK) { delete s; return rc; }
         *out = s;
         return RACC_HIP_OK;
