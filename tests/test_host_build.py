@@ -95,3 +95,17 @@ def test_path_tracer_shared_arithmetic():
     assert u.min() >= 0.0 and u.max() < 1.0 and np.all(u * (1 << 24) == np.floor(u * (1 << 24)))
     hist = np.bincount((u * 64).astype(int), minlength=64)
     assert hist.min() > 0.9 * len(u) / 64 and hist.max() < 1.1 * len(u) / 64 and abs(u.mean() - 0.5) < 2e-3
+
+
+def test_build_is_identical_for_any_thread_count(monkeypatch):
+    """The thread-pool build allocates provisional node ids in timing-dependent order; the renumber pass must make the
+    blobs byte-identical to the single-threaded build (and therefore to the oracle's)."""
+    sc = synth.battlefield_synth(grid=96, boxes=300, quads=1500)          # ~26k triangles: several pool tasks
+    blobs = {}
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("RACC_BUILD_THREADS", threads)
+        h = ra.HostScene(sc["vertices"], sc["indices"])
+        blobs[threads] = (h.nodes.tobytes(), h.pairs.tobytes(), h.remap.tobytes())
+    assert blobs["1"] == blobs["3"] == blobs["8"]
+    ref = orc.build_scene(sc["vertices"], sc["indices"])
+    assert blobs["8"][0] == ref["nodes"].tobytes() and blobs["8"][1] == ref["pairs"].tobytes() and blobs["8"][2] == ref["remap"].tobytes()
