@@ -146,15 +146,22 @@ extern "C" int racc_ptdev_render_file(const char* scene_bin, int device, uint32_
 
     int rc = 0;
     racc_hip_ctx* ctx = nullptr; racc_host_scene* host = nullptr; racc_hip_scene* scene = nullptr; racc_hip_env* env = nullptr;
-    hipStream_t stream = nullptr;
-    uint32_t *dSample[2] = {nullptr, nullptr}, *dCount = nullptr, *hCount = nullptr;
+    // Two pipelines, each a lane of the engine with its own HIP stream and buffers: sample batches are independent, so while
+    // one pipeline's launch drains (its last long rays) the other's next launch fills the machine.
+    constexpr int kPipes = 2;
+    struct Pipe {
+        hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+        RayRec* rays[2] = {nullptr, nullptr}; PathRec* paths[2] = {nullptr, nullptr}; uint32_t* sample[2] = {nullptr, nullptr};
+        HitRec* hits = nullptr; uint32_t* dCount = nullptr; uint32_t* hCount = nullptr;
+        int cur = 0; uint32_t n = 0; bool busy = false;
+    } pipe[kPipes];
     ShadeTri* dTris = nullptr;
-    RayRec* dRays[2] = {nullptr, nullptr}; PathRec* dPaths[2] = {nullptr, nullptr}; HitRec* dHits = nullptr;
     unsigned long long* dFrame = nullptr;
     uint64_t raysTraced = 0, primaries = 0; uint32_t rounds = 0;
     double seconds = 0.0;
     const size_t cap = size_t(perSample) * S;
     const size_t frameWords = size_t(width) * height * 3;
+    const int pipes = (spp_count + S - 1) / S > 1 ? kPipes : 1;
     if (perSample == 0) {   // nothing to render (viewport smaller than one tile): an all-zero image, like the host consumer
         for (size_t i = 0; i < frameWords; ++i) rgb_sum[i] = 0.0;
         goto fill;
@@ -162,7 +169,7 @@ extern "C" int racc_ptdev_render_file(const char* scene_bin, int device, uint32_
     {
         racc_hip_options opts{};
         opts.struct_size = sizeof(opts);
-        opts.lanes = 1;
+        opts.lanes = kPipes;
         PT_RACC(racc_hip_create(device, &opts, &ctx));
         PT_RACC(racc_host_scene_build(sc.vertices.data(), V, sc.indices.data(), T * 3, &host));
         const void *nodes = nullptr, *pairs = nullptr; const uint32_t* remap = nullptr;
@@ -173,7 +180,6 @@ extern "C" int racc_ptdev_render_file(const char* scene_bin, int device, uint32_
         PT_RACC(racc_hip_env_upload(ctx, sc.env.data(), sc.hdr.environmentWidth, sc.hdr.environmentHeight, &env));
 
         PT_HIP(hipSetDevice(device));
-        PT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         {
             const SceneView hostView{sc.indices.data(), sc.triangleMaterials.data(), sc.normals.data(), sc.vertices.data(), T};
             std::vector<ShadeTri> tris(T);
@@ -181,14 +187,19 @@ extern "C" int racc_ptdev_render_file(const char* scene_bin, int device, uint32_
             PT_HIP(hipMalloc(&dTris, size_t(T) * sizeof(ShadeTri)));
             PT_HIP(hipMemcpy(dTris, tris.data(), size_t(T) * sizeof(ShadeTri), hipMemcpyHostToDevice));
         }
-        for (int k = 0; k < 2; ++k) {
-            PT_HIP(hipMalloc(&dRays[k], cap * sizeof(RayRec)));
-            PT_HIP(hipMalloc(&dPaths[k], cap * sizeof(PathRec)));
-            PT_HIP(hipMalloc(&dSample[k], cap * 4));
+        for (int p = 0; p < pipes; ++p) {
+            Pipe& P = pipe[p];
+            PT_HIP(hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
+            PT_HIP(hipEventCreateWithFlags(&P.done, hipEventDisableTiming));
+            for (int k = 0; k < 2; ++k) {
+                PT_HIP(hipMalloc(&P.rays[k], cap * sizeof(RayRec)));
+                PT_HIP(hipMalloc(&P.paths[k], cap * sizeof(PathRec)));
+                PT_HIP(hipMalloc(&P.sample[k], cap * 4));
+            }
+            PT_HIP(hipMalloc(&P.hits, cap * sizeof(HitRec)));
+            PT_HIP(hipMalloc(&P.dCount, 4));
+            PT_HIP(hipHostMalloc(&P.hCount, 4));
         }
-        PT_HIP(hipMalloc(&dHits, cap * sizeof(HitRec)));
-        PT_HIP(hipMalloc(&dCount, 4));
-        PT_HIP(hipHostMalloc(&hCount, 4));
         PT_HIP(hipMalloc(&dFrame, frameWords * 8));
         PT_HIP(hipMemset(dFrame, 0, frameWords * 8));
         PT_HIP(hipDeviceSynchronize());
@@ -197,33 +208,61 @@ extern "C" int racc_ptdev_render_file(const char* scene_bin, int device, uint32_
         PT_HIP(hipGetDeviceProperties(&prop, device));
         const uint32_t maxBlocks = uint32_t(prop.multiProcessorCount) * 8u;
         const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t s0 = 0; s0 < spp_count; s0 += S) {
-            const uint32_t ns = (spp_count - s0 < S) ? spp_count - s0 : S;
-            uint32_t n = uint32_t(perSample * ns);
-            int cur = 0;
-            {
-                const uint32_t blocks = (n + 255u) / 256u < maxBlocks ? (n + 255u) / 256u : maxBlocks;
-                hipLaunchKernelGGL(ptGenKernel, dim3(blocks), dim3(256), 0, stream, sc.cam, width, regionW, regionH, spp_first + s0, ns,
-                                   dRays[cur], dPaths[cur], dSample[cur]);
+        uint32_t s0 = 0;            // next sample batch to start
+        int live = 0;
+        // One bounce of pipeline P: trace, shade + compact into the other buffer, read the survivor count back; `done` fires
+        // when the count has landed.
+        auto bounce = [&](int p) -> int {
+            Pipe& P = pipe[p];
+            if (racc_hip_intersect_device(ctx, scene, env, P.rays[P.cur], P.hits, P.n, uint32_t(p), P.stream) != RACC_HIP_OK) return -3;
+            raysTraced += P.n; ++rounds;
+            if (hipMemsetAsync(P.dCount, 0, 4, P.stream) != hipSuccess) return -4;
+            const uint32_t need = (P.n + uint32_t(kShadeBlock) - 1u) / uint32_t(kShadeBlock);
+            const uint32_t blocks = need < uint32_t(prop.multiProcessorCount) * 2u ? need : uint32_t(prop.multiProcessorCount) * 2u;
+            hipLaunchKernelGGL(ptShadeKernel, dim3(blocks), dim3(kShadeBlock), 0, P.stream, dTris, T, sc.mat, depthLimit,
+                               P.rays[P.cur], P.hits, P.paths[P.cur], P.sample[P.cur], P.n, P.rays[P.cur ^ 1], P.paths[P.cur ^ 1], P.sample[P.cur ^ 1],
+                               P.dCount, dFrame);
+            if (hipGetLastError() != hipSuccess) return -4;
+            if (hipMemcpyAsync(P.hCount, P.dCount, 4, hipMemcpyDeviceToHost, P.stream) != hipSuccess) return -4;
+            if (hipEventRecord(P.done, P.stream) != hipSuccess) return -4;
+            return 0;
+        };
+        for (;;) {
+            for (int p = 0; p < pipes; ++p) {          // start a new sample batch on every idle pipeline
+                Pipe& P = pipe[p];
+                if (P.busy || s0 >= spp_count) continue;
+                const uint32_t ns = (spp_count - s0 < S) ? spp_count - s0 : S;
+                P.n = uint32_t(perSample * ns); P.cur = 0;
+                const uint32_t blocks = (P.n + 255u) / 256u < maxBlocks ? (P.n + 255u) / 256u : maxBlocks;
+                hipLaunchKernelGGL(ptGenKernel, dim3(blocks), dim3(256), 0, P.stream, sc.cam, width, regionW, regionH, spp_first + s0, ns,
+                                   P.rays[0], P.paths[0], P.sample[0]);
                 PT_HIP(hipGetLastError());
+                primaries += P.n;
+                s0 += ns;
+                if (int e = bounce(p)) { std::fprintf(stderr, "racc_ptdev: bounce failed: %s\n", racc_hip_last_error()); rc = e; goto done; }
+                P.busy = true; ++live;
             }
-            primaries += n;
-            while (n) {
-                PT_RACC(racc_hip_intersect_device(ctx, scene, env, dRays[cur], dHits, n, 0, stream));
-                raysTraced += n; ++rounds;
-                PT_HIP(hipMemsetAsync(dCount, 0, 4, stream));
-                const uint32_t need = (n + uint32_t(kShadeBlock) - 1u) / uint32_t(kShadeBlock);
-                const uint32_t blocks = need < uint32_t(prop.multiProcessorCount) * 2u ? need : uint32_t(prop.multiProcessorCount) * 2u;
-                hipLaunchKernelGGL(ptShadeKernel, dim3(blocks), dim3(kShadeBlock), 0, stream, dTris, T, sc.mat, depthLimit,
-                                   dRays[cur], dHits, dPaths[cur], dSample[cur], n, dRays[cur ^ 1], dPaths[cur ^ 1], dSample[cur ^ 1], dCount, dFrame);
-                PT_HIP(hipGetLastError());
-                PT_HIP(hipMemcpyAsync(hCount, dCount, 4, hipMemcpyDeviceToHost, stream));
-                PT_HIP(hipStreamSynchronize(stream));
-                n = *hCount;
-                cur ^= 1;
+            if (!live) break;
+            // wait for whichever pipeline finishes its bounce first (poll; block on one when it is the only one)
+            int ready = -1;
+            while (ready < 0) {
+                for (int p = 0; p < pipes && ready < 0; ++p)
+                    if (pipe[p].busy) {
+                        const hipError_t q = live == 1 ? hipEventSynchronize(pipe[p].done) : hipEventQuery(pipe[p].done);
+                        if (q == hipSuccess) ready = p;
+                        else if (q != hipErrorNotReady) { std::fprintf(stderr, "racc_ptdev: %s\n", hipGetErrorString(q)); rc = -4; goto done; }
+                    }
+            }
+            Pipe& P = pipe[ready];
+            P.n = *P.hCount;
+            P.cur ^= 1;
+            if (P.n) {
+                if (int e = bounce(ready)) { std::fprintf(stderr, "racc_ptdev: bounce failed: %s\n", racc_hip_last_error()); rc = e; goto done; }
+            } else {
+                P.busy = false; --live;
             }
         }
-        PT_HIP(hipStreamSynchronize(stream));
+        PT_HIP(hipDeviceSynchronize());
         seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::vector<long long> frame(frameWords);
         PT_HIP(hipMemcpy(frame.data(), dFrame, frameWords * 8, hipMemcpyDeviceToHost));
@@ -237,13 +276,18 @@ fill:
     }
 done:
     if (host) racc_host_scene_free(host);
-    for (int k = 0; k < 2; ++k) { if (dRays[k]) hipFree(dRays[k]); if (dPaths[k]) hipFree(dPaths[k]); if (dSample[k]) hipFree(dSample[k]); }
-    if (dHits) hipFree(dHits);
-    if (dCount) hipFree(dCount);
-    if (hCount) hipHostFree(hCount);
+    if (rc != 0) hipDeviceSynchronize();     // nothing may still be writing into the buffers freed below
+    for (int p = 0; p < kPipes; ++p) {
+        Pipe& P = pipe[p];
+        for (int k = 0; k < 2; ++k) { if (P.rays[k]) hipFree(P.rays[k]); if (P.paths[k]) hipFree(P.paths[k]); if (P.sample[k]) hipFree(P.sample[k]); }
+        if (P.hits) hipFree(P.hits);
+        if (P.dCount) hipFree(P.dCount);
+        if (P.hCount) hipHostFree(P.hCount);
+        if (P.done) hipEventDestroy(P.done);
+        if (P.stream) hipStreamDestroy(P.stream);
+    }
     if (dFrame) hipFree(dFrame);
     if (dTris) hipFree(dTris);
-    if (stream) hipStreamDestroy(stream);
     if (env) racc_hip_env_free(ctx, env);
     if (scene) racc_hip_scene_free(ctx, scene);
     if (ctx) racc_hip_destroy(ctx);
