@@ -71,7 +71,6 @@ struct TraverseArgs {
     uint32_t tailActive;      // V2: waves with at most this many live rays run inner AND leaf bodies every iteration
     uint32_t thinReps;        // V2: inner steps per scheduling iteration in such waves
     uint32_t innerReps;       // V2: inner steps per scheduling iteration in all other waves
-    uint32_t splitActive, splitAge, splitBudget;   // V5: split when <= splitActive rays are live, only rays older than splitAge drain steps, <= splitBudget donations per iteration
     unsigned long long* stats;   // STATS builds only: [0] inner iters [1] inner lanes [2] leaf iters [3] leaf lanes
                                  //                    [4] refill iters [5] rays loaded [6] dequeues [7] waves
 };
@@ -113,11 +112,8 @@ struct LaneRay {
 };
 
 // Triangle-pair test, Kernels.h:36-115.  Updates the lane's hit and returns the new tFar.
-// WANT_BOTH: also report whether BOTH triangles of the pair passed their range tests (the drain-splitting kernel needs it).
-template <bool WANT_BOTH>
-__device__ __forceinline__ float pairIntersectDataT(const float4 t0, const float4 t1, const float4 t2, uint32_t index, LaneRay& r, bool& both) {
+__device__ __forceinline__ float pairIntersectData(const float4 t0, const float4 t1, const float4 t2, uint32_t index, LaneRay& r) {
     const float tNear = r.tNear, tMax = r.tFar;
-    if (WANT_BOTH) both = false;
 
     // n1 = e1 x e2, n2 = e3 x e1 (mad_cross, Kernels.h:23-25)
     const float n1x = __builtin_fmaf(t0.y, t1.z, -(t0.z * t1.y));
@@ -157,7 +153,6 @@ __device__ __forceinline__ float pairIntersectDataT(const float4 t0, const float
     outside1 = outside1 || (W1 < 0.0f || T1 <= absDet1 * tNear || T1 > absDet1 * tMax);
     outside2 = outside2 || (W2 < 0.0f || T2 <= absDet2 * tNear || T2 > absDet2 * tMax);
     if (outside1 && outside2) return tMax;
-    if (WANT_BOTH) both = !outside1 && !outside2;
 
     uint32_t which = 0;
     if ((!outside2 && outside1) || (!outside1 && !outside2 && T1 * absDet2 > T2 * absDet1)) {
@@ -170,11 +165,6 @@ __device__ __forceinline__ float pairIntersectDataT(const float4 t0, const float
     r.hitU = U1 * rcp;
     r.hitV = V1 * rcp;
     return t;
-}
-
-__device__ __forceinline__ float pairIntersectData(const float4 t0, const float4 t1, const float4 t2, uint32_t index, LaneRay& r) {
-    bool both;
-    return pairIntersectDataT<false>(t0, t1, t2, index, r, both);
 }
 
 __device__ __forceinline__ float pairIntersect(const float4* __restrict__ pairs, uint32_t index, LaneRay& r) {
@@ -929,384 +919,6 @@ __global__ void __launch_bounds__(BLOCK) traverseKernelV4(const TraverseArgs a) 
     }
 }
 
-// ================================================================================================ V5
-// V2 plus ray splitting in the drain.  A launch ends on its longest rays: a ray is a dependent chain of node visits
-// (≈0.3 us each for a lone wave) and the longest one of a batch has ≈330.  Once a wave has no more rays to load, idle lanes
-// take the OLDEST stack entry of a running ray — the subtree the reference would visit last — and traverse it concurrently
-// with the donor's current tFar.  The result stays the reference's, bit for bit:
-//   * the fragments of a ray are totally ordered (owner first, then the donated subtrees from the LATEST donation to the
-//     first); the owner runs with the true tFar, a helper with a LOOSER one, so it visits a superset of the nodes and tests
-//     a superset of the pairs of the sequential run;
-//   * when all fragments are done they are folded in that order.  A helper's run equals its sequential run with
-//     tFar = c (the fold so far) unless c falls into a "danger interval" recorded at a pair the helper accepted:
-//     [t(1-eps), max(leaf entry distance, t(1+eps))] — there the reference's scaled compare T <= |det| * tFar
-//     (Kernels.h:88-89) or its box-entry sentinel (Kernels.h:131-134) could have decided differently (inf if both
-//     triangles of the pair passed);
-//   * if it does, the ray is traced again, unsplit.
-// oracle/split_sim.c is the CPU prototype of exactly this (checked ray by ray against the sequential traversal).
-// A helper needs the entry distance of a leaf it pops from its stack; instead of a second stack word, a leaf pushed as the
-// far child is stored as "replay this node, side s" and the node's slab test is simply run again when it is popped.
-constexpr uint32_t kWait = 2u;              // finished fragment of a split ray, waiting for the fold
-constexpr uint32_t kReplayBit = 0x40000000u, kReplaySide = 0x20000000u, kNodeIndexMask = 0x1FFFFFFFu;
-
-template <int BLOCK, int LDS_LEVELS, bool STATS>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) traverseKernelV5(const TraverseArgs a) {
-    __shared__ uint32_t lds[LDS_LEVELS * BLOCK];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t waveTid0 = uint32_t(__builtin_amdgcn_readfirstlane(int(tid & ~63u)));
-    uint32_t* const myLds = lds + tid;
-
-    LaneRay r;
-    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = 0.0f;
-    r.ix = r.iy = r.iz = r.ex = r.ey = r.ez = 0.0f;
-    r.tNear = r.tFar = 0.0f; r.hitIndex = -1; r.hitU = r.hitV = 0.0f;
-    uint32_t rayIdx = 0;
-    uint32_t node = kEmpty;
-    uint32_t sp = 0;
-    uint32_t wBeg = min((blockIdx.x * uint32_t(BLOCK / 64) + uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6)))) * a.chunk, a.count);
-    uint32_t wEnd = min(wBeg + a.chunk, a.count);
-    bool exhausted = false;
-    uint32_t stInner = 0, stInnerLanes = 0, stLeaf = 0, stLeafLanes = 0, stRefill = 0, stLoaded = 0, stDeq = 0, stDonations = 0, stFallbacks = 0;
-    unsigned long long cyStart = 0;
-    if (STATS) cyStart = __builtin_readcyclecounter();
-
-#define RACC5_EPILOGUE()                                                                                               \
-    do {                                                                                                               \
-        float4 out;                                                                                                    \
-        if (r.hitIndex < 0) {                                                                                          \
-            out = a.env ? make_float4(__uint_as_float(kInvalidTriangle), r.dx, r.dy, r.dz)                             \
-                        : make_float4(__uint_as_float(kInvalidTriangle), 0.0f, 0.0f, 0.0f);                            \
-        } else {                                                                                                       \
-            uint32_t m = a.remap[r.hitIndex];                                                                          \
-            const uint32_t edge = m >> 30;                                                                             \
-            m &= 0x3FFFFFFFu;                                                                                          \
-            const float bx = r.hitU, by = r.hitV, bz = 1.0f - r.hitU - r.hitV;                                         \
-            float u = bx, v = by;                                                                                      \
-            if (edge == 1u) { u = bz; v = bx; } else if (edge == 2u) { u = by; v = bz; }                               \
-            out = make_float4(__uint_as_float(m), r.tFar, u, v);                                                       \
-        }                                                                                                              \
-        a.results[rayIdx] = out;                                                                                       \
-        node = kEmpty;                                                                                                 \
-    } while (0)
-    // (Re)starts ray `idx` in this lane; returns false (result already written) for an invalid ray.
-#define RACC5_LOAD(idx_, ok_)                                                                                          \
-    do {                                                                                                               \
-        const float4 q0 = a.rays[size_t(idx_) * 2 + 0];                                                                \
-        const float4 q1 = a.rays[size_t(idx_) * 2 + 1];                                                                \
-        const bool valid = isfinite(q0.x) && isfinite(q0.y) && isfinite(q0.z) && isfinite(q0.w) &&                     \
-                           isfinite(q1.x) && isfinite(q1.y) && isfinite(q1.z) && !isnan(q1.w);                         \
-        ok_ = valid;                                                                                                   \
-        if (!valid) {                                                                                                  \
-            a.results[idx_] = make_float4(__uint_as_float(kInvalidTriangle), a.env ? __uint_as_float(0x7FC00000u) : 0.0f, 0.0f, 0.0f); \
-        } else {                                                                                                       \
-            const float eps = 1e-10f;                                                                                  \
-            r.ox = q0.x; r.oy = q0.y; r.oz = q0.z; r.tNear = q0.w;                                                     \
-            r.dx = (fabsf(q1.x) < eps) ? copysignf(eps, q1.x) : q1.x;                                                  \
-            r.dy = (fabsf(q1.y) < eps) ? copysignf(eps, q1.y) : q1.y;                                                  \
-            r.dz = (fabsf(q1.z) < eps) ? copysignf(eps, q1.z) : q1.z;                                                  \
-            r.tFar = q1.w;                                                                                             \
-            r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;                                                \
-            r.ex = -r.ox * r.ix; r.ey = -r.oy * r.iy; r.ez = -r.oz * r.iz;                                             \
-            r.hitIndex = -1; r.hitU = 0.0f; r.hitV = 0.0f;                                                             \
-            rayIdx = idx_;                                                                                             \
-            node = 0x80000000u;                                                                                        \
-            sp = 0;                                                                                                    \
-        }                                                                                                              \
-    } while (0)
-
-    // ---------------------------------------------------------------- main phase: exactly V2's loop, until the wave runs dry
-    for (uint32_t iter = 0;; ++iter) {
-        if (iter >= a.maxIters) {
-            if (lane == 0) atomicAdd(a.cursor + 2, 1u);
-            goto finish;
-        }
-        const uint32_t nInner = __popcll(__ballot(int(node) < 0));
-        const uint32_t nLeaf = __popcll(__ballot(int(node) >= int(kLeafBase)));
-        const bool noWork = (nInner | nLeaf) == 0u;
-        const bool refill = noWork || (64u - nInner - nLeaf) >= a.refillMin;
-        if (refill) {
-            if (node == kDone) RACC5_EPILOGUE();
-            const uint64_t emptyMask = __ballot(node == kEmpty);
-            const uint32_t need = __popcll(emptyMask);
-            if (STATS) ++stRefill;
-            if (wBeg == wEnd) {
-                if (STATS) ++stDeq;
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(a.cursor, a.chunk);
-                const uint32_t rr = __builtin_amdgcn_readfirstlane(b);
-                b = rr + gridDim.x * uint32_t(BLOCK / 64) * a.chunk;
-                if (b < rr) b = 0xFFFFFFFFu;
-                exhausted = (b >= a.count) || (b + a.chunk < b);
-                wBeg = exhausted ? a.count : b;
-                wEnd = exhausted ? a.count : min(b + a.chunk, a.count);
-            }
-            const uint32_t take = min(need, wEnd - wBeg);
-            const uint32_t rank = laneRank(emptyMask);
-            if (node == kEmpty && rank < take) {
-                const uint32_t idx = wBeg + rank;
-                bool ok;
-                RACC5_LOAD(idx, ok);
-                (void)ok;
-            }
-            wBeg += take;
-            if (STATS) stLoaded += take;
-            if (exhausted && wBeg == wEnd) break;          // nothing left to load: go and drain
-            continue;
-        }
-        const uint32_t nActive = nInner + nLeaf;
-        const bool doLeaf = nLeaf >= a.leafMin || nInner == 0u || nLeaf * 4u >= nActive;
-        const bool doInner = nInner != 0u && (!doLeaf || nActive <= a.tailActive);
-        if (doLeaf) {
-            if (STATS) { ++stLeaf; stLeafLanes += nLeaf; }
-            if (int(node) >= int(kLeafBase)) {
-                const uint32_t cur = node & 0xFFFFFFu;
-                const uint32_t cnt = node >> 24;
-                r.tFar = pairIntersectData(a.pairs[cur * 3u], a.pairs[cur * 3u + 1u], a.pairs[cur * 3u + 2u], cur, r);
-                if (cnt > 1u) node = ((cnt - 1u) << 24) | (cur + 1u);
-                else if (sp == 0u) node = kDone;
-                else { --sp; node = myLds[sp * BLOCK]; }
-            }
-        }
-        if (doInner) {
-            const uint32_t reps = nActive <= a.tailActive ? a.thinReps : a.innerReps;
-            for (uint32_t rep = 0;; ++rep) {
-                if (STATS) { ++stInner; stInnerLanes += uint32_t(__popcll(__ballot(int(node) < 0))); }
-                if (int(node) < 0) {
-                    const float4* np = a.nodes + size_t(node & 0x7FFFFFFFu) * 4;
-                    const uint2 kids = *reinterpret_cast<const uint2*>(np);
-                    const float4 d1 = np[1], d2 = np[2], d3 = np[3];
-                    asm volatile("" :: "v"(kids.x), "v"(kids.y));
-                    const float tRay = r.tFar;
-                    float tFirst, tLast;
-                    slabPair(d1, d2, d3, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tNear, tRay, tFirst, tLast);
-                    const float firstDiff = tRay - tFirst, lastDiff = tRay - tLast;
-                    if (firstDiff + lastDiff != 0.0f) {
-                        const bool lastNearer = tLast < tFirst;
-                        if (tFirst != tRay && tLast != tRay) { myLds[sp * BLOCK] = lastNearer ? kids.x : kids.y; ++sp; }
-                        node = lastNearer ? kids.y : kids.x;
-                    } else if (sp == 0u) {
-                        node = kDone;
-                    } else {
-                        --sp; node = myLds[sp * BLOCK];
-                    }
-                }
-                if (rep + 1u >= reps || __ballot(int(node) < 0) == 0ull) break;
-            }
-        }
-    }
-
-    // ---------------------------------------------------------------- drain phase: no more rays to load; split the long ones
-    {
-        uint32_t base = 0;            // owner: stack bottom (entries below it were donated)
-        uint32_t helper = 0;          // this lane traverses a donated subtree of lane `root`'s ray
-        uint32_t root = 0;
-        uint32_t seq = 0;             // helper: donation number (1 = first = last in traversal order); owner: donations made
-        uint32_t pending = 0;         // owner: helpers still running
-        uint32_t noSplit = 0;         // owner: traced again unsplit after a fallback
-        uint32_t nAcc = 0;            // helper: pairs accepted so far (saturates at 2)
-        float curT0 = -INFINITY;      // helper: entry distance of the current node (-inf for the donated root)
-        uint32_t age = 0;             // steps this lane's ray (or fragment) has taken in the drain: only old rays are worth splitting
-        float lastLo = 0.0f, lastHi = 0.0f, oldLo = 0.0f, oldHi = 0.0f;
-        const float kEps = 1.0f / 1048576.0f;
-        const bool forceFallback = (a.regroup & 1u) != 0u;     // test hook: every fold re-traces its ray
-
-        for (uint32_t iter = 0;; ++iter) {
-            if (iter >= a.maxIters) {
-                if (lane == 0) atomicAdd(a.cursor + 2, 1u);
-                break;
-            }
-            // ---- completion of fragments and unsplit rays
-            const uint64_t doneMask = __ballot(node == kDone);
-            if (doneMask) {
-                uint64_t hm = __ballot(node == kDone && helper != 0u);
-                while (hm) {                                       // each finished helper reports to its owner
-                    const int h = __ffsll((long long)hm) - 1;
-                    hm &= hm - 1;
-                    const uint32_t rl = uint32_t(__builtin_amdgcn_readlane(int(root), h));
-                    if (lane == rl) --pending;
-                }
-                if (node == kDone) {
-                    if (helper != 0u || seq != 0u) node = kWait;   // a fragment of a split ray: wait for the fold
-                    else RACC5_EPILOGUE();                         // an unsplit ray: write it out, the lane can help now
-                }
-            }
-            // ---- fold the split rays whose fragments are all done
-            uint64_t fm = __ballot(helper == 0u && node == kWait && pending == 0u);
-            while (fm) {
-                const int R = __ffsll((long long)fm) - 1;
-                fm &= fm - 1;
-                float c = __uint_as_float(uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(r.tFar)), R)));
-                int bestIdx = __builtin_amdgcn_readlane(r.hitIndex, R);
-                uint32_t bestU = uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(r.hitU)), R));
-                uint32_t bestV = uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(r.hitV)), R));
-                const uint32_t nDon = uint32_t(__builtin_amdgcn_readlane(int(seq), R));
-                bool fallback = forceFallback;
-                for (uint32_t d = nDon; d >= 1u && !fallback; --d) {          // latest donation first = traversal order
-                    const uint64_t sel = __ballot(helper != 0u && root == uint32_t(R) && seq == d);
-                    if (!sel) { fallback = true; break; }                    // cannot happen; be safe
-                    const int h = __ffsll((long long)sel) - 1;
-                    const uint32_t acc = uint32_t(__builtin_amdgcn_readlane(int(nAcc), h));
-                    if (acc == 0u) continue;
-                    const float lLo = __uint_as_float(uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(lastLo)), h)));
-                    const float lHi = __uint_as_float(uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(lastHi)), h)));
-                    const float oLo = __uint_as_float(uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(oldLo)), h)));
-                    const float oHi = __uint_as_float(uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(oldHi)), h)));
-                    if (c >= lLo && c <= lHi) { fallback = true; break; }
-                    if (acc > 1u && c >= oLo && c <= oHi) { fallback = true; break; }
-                    if (c > lHi) {
-                        c = __uint_as_float(uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(r.tFar)), h)));
-                        bestIdx = __builtin_amdgcn_readlane(r.hitIndex, h);
-                        bestU = uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(r.hitU)), h));
-                        bestV = uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(r.hitV)), h));
-                    } else if (acc > 1u && c > oHi) { fallback = true; break; }
-                }
-                if (helper != 0u && root == uint32_t(R)) {         // the helpers are free again
-                    node = kEmpty; helper = 0u; seq = 0u; nAcc = 0u;
-                }
-                if (lane == uint32_t(R)) {
-                    seq = 0u; base = 0u;
-                    if (!fallback) {
-                        r.tFar = c; r.hitIndex = bestIdx; r.hitU = __uint_as_float(bestU); r.hitV = __uint_as_float(bestV);
-                        node = kDone;                              // written out by the next iteration's completion step
-                    } else {
-                        bool ok;
-                        const uint32_t idx = rayIdx;
-                        RACC5_LOAD(idx, ok);
-                        (void)ok;                                  // it was valid the first time
-                        noSplit = 1u; age = 0u;
-                        if (STATS) ++stFallbacks;
-                    }
-                }
-            }
-            const bool isInner = int(node) < 0, isLeaf = int(node) >= int(kLeafBase);
-            const uint32_t nInner = __popcll(__ballot(isInner));
-            const uint32_t nLeaf = __popcll(__ballot(isLeaf));
-            const uint32_t nActive = nInner + nLeaf;
-            if (nActive == 0u) {
-                if (__ballot(node != kEmpty) == 0ull) break;       // everything written out
-                continue;                                          // a fold just produced kDone lanes: next iteration
-            }
-            // ---- donation: the oldest stack entry of a running ray goes to an idle lane
-            if (nActive <= a.splitActive) {
-                uint64_t idle = __ballot(node == kEmpty);
-                uint64_t donors = __ballot(helper == 0u && noSplit == 0u && (isInner || isLeaf) && sp > base && seq < 15u && isfinite(r.tFar) && age >= a.splitAge);
-                uint32_t budget = a.splitBudget;
-                while (idle && donors && budget--) {
-                    const int d = __ffsll((long long)donors) - 1, h = __ffsll((long long)idle) - 1;
-                    donors &= donors - 1; idle &= idle - 1;
-                    const uint32_t dBase = uint32_t(__builtin_amdgcn_readlane(int(base), d));
-                    const uint32_t dSeq = uint32_t(__builtin_amdgcn_readlane(int(seq), d)) + 1u;
-#define RACC5_BCAST_F(x) __uint_as_float(uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(x)), d)))
-                    const float vox = RACC5_BCAST_F(r.ox), voy = RACC5_BCAST_F(r.oy), voz = RACC5_BCAST_F(r.oz);
-                    const float vdx = RACC5_BCAST_F(r.dx), vdy = RACC5_BCAST_F(r.dy), vdz = RACC5_BCAST_F(r.dz);
-                    const float vix = RACC5_BCAST_F(r.ix), viy = RACC5_BCAST_F(r.iy), viz = RACC5_BCAST_F(r.iz);
-                    const float vex = RACC5_BCAST_F(r.ex), vey = RACC5_BCAST_F(r.ey), vez = RACC5_BCAST_F(r.ez);
-                    const float vtn = RACC5_BCAST_F(r.tNear), vtf = RACC5_BCAST_F(r.tFar);
-#undef RACC5_BCAST_F
-                    const uint32_t vIdx = uint32_t(__builtin_amdgcn_readlane(int(rayIdx), d));
-                    if (lane == uint32_t(h)) {
-                        r.ox = vox; r.oy = voy; r.oz = voz; r.dx = vdx; r.dy = vdy; r.dz = vdz;
-                        r.ix = vix; r.iy = viy; r.iz = viz; r.ex = vex; r.ey = vey; r.ez = vez;
-                        r.tNear = vtn; r.tFar = vtf; r.hitIndex = -1; r.hitU = 0.0f; r.hitV = 0.0f;
-                        rayIdx = vIdx;
-                        node = lds[dBase * BLOCK + waveTid0 + uint32_t(d)];      // the donor's bottom entry
-                        sp = 0u; base = 0u; helper = 1u; root = uint32_t(d); seq = dSeq; pending = 0u; noSplit = 0u; nAcc = 0u;
-                        curT0 = -INFINITY; age = a.splitAge;       // a helper may be asked for help in turn? no: helpers never donate
-                    }
-                    if (lane == uint32_t(d)) { ++base; seq = dSeq; ++pending; }
-                    if (STATS) ++stDonations;
-                }
-            }
-            // ---- the step bodies, under V2's vote (helpers that just started count)
-            const bool isLeaf2 = int(node) >= int(kLeafBase);
-            const uint32_t nLeaf2 = __popcll(__ballot(isLeaf2)), nInner2 = __popcll(__ballot(int(node) < 0)), nActive2 = nLeaf2 + nInner2;
-            const bool thin = nActive2 <= a.tailActive;
-            const bool doLeaf = nLeaf2 >= a.leafMin || nInner2 == 0u || nLeaf2 * 4u >= nActive2;
-            const bool doInner = nInner2 != 0u && (!doLeaf || thin);
-            if (doLeaf) {
-                if (STATS) { ++stLeaf; stLeafLanes += nLeaf2; }
-                if (isLeaf2) {
-                    ++age;
-                    const uint32_t cur = node & 0xFFFFFFu;
-                    const uint32_t cnt = node >> 24;
-                    const float before = r.tFar;
-                    const int idxBefore = r.hitIndex;
-                    bool both;
-                    r.tFar = pairIntersectDataT<true>(a.pairs[cur * 3u], a.pairs[cur * 3u + 1u], a.pairs[cur * 3u + 2u], cur, r, both);
-                    if (helper != 0u && (r.hitIndex != idxBefore || r.tFar != before)) {     // accepted: record the danger interval
-                        if (nAcc == 1u) { oldLo = lastLo; oldHi = lastHi; }
-                        else if (nAcc > 1u) { oldLo = fminf(oldLo, lastLo); oldHi = fmaxf(oldHi, lastHi); }
-                        const float t = r.tFar;
-                        lastLo = t * (1.0f - kEps) - 1.17549435e-38f;
-                        lastHi = both ? INFINITY : fmaxf(curT0, t * (1.0f + kEps) + 1.17549435e-38f);
-                        nAcc = nAcc < 2u ? nAcc + 1u : 2u;
-                    }
-                    if (cnt > 1u) node = ((cnt - 1u) << 24) | (cur + 1u);
-                    else if (sp == base) node = kDone;
-                    else { --sp; node = myLds[sp * BLOCK]; }
-                }
-            }
-            const uint32_t reps = thin ? a.thinReps : a.innerReps;
-            if (doInner) for (uint32_t rep = 0;; ++rep) {
-                const bool in = int(node) < 0;
-                if (__ballot(in) == 0ull) break;
-                if (STATS) { ++stInner; stInnerLanes += uint32_t(__popcll(__ballot(in))); }
-                if (in) {
-                    ++age;
-                    const bool replay = (node & kReplayBit) != 0u;
-                    const float4* np = a.nodes + size_t(node & kNodeIndexMask) * 4;
-                    const uint2 kids = *reinterpret_cast<const uint2*>(np);
-                    const float4 d1 = np[1], d2 = np[2], d3 = np[3];
-                    asm volatile("" :: "v"(kids.x), "v"(kids.y));
-                    const float tRay = replay ? INFINITY : r.tFar;
-                    float tFirst, tLast;
-                    slabPair(d1, d2, d3, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tNear, tRay, tFirst, tLast);
-                    if (replay) {                                  // a leaf that was pushed as "node, side": now its entry distance is known
-                        const bool side = (node & kReplaySide) != 0u;
-                        node = side ? kids.y : kids.x;
-                        curT0 = side ? tLast : tFirst;
-                    } else {
-                        const float firstDiff = tRay - tFirst, lastDiff = tRay - tLast;
-                        if (firstDiff + lastDiff != 0.0f) {
-                            const bool lastNearer = tLast < tFirst;
-                            if (tFirst != tRay && tLast != tRay) {
-                                uint32_t far = lastNearer ? kids.x : kids.y;
-                                if (helper != 0u && int(far) >= int(kLeafBase))
-                                    far = (node & (0x80000000u | kNodeIndexMask)) | kReplayBit | (lastNearer ? 0u : kReplaySide);
-                                myLds[sp * BLOCK] = far; ++sp;
-                            }
-                            node = lastNearer ? kids.y : kids.x;
-                            curT0 = lastNearer ? tLast : tFirst;
-                        } else if (sp == base) {
-                            node = kDone;
-                        } else {
-                            --sp; node = myLds[sp * BLOCK];
-                        }
-                    }
-                }
-                if (rep + 1u >= reps) break;
-            }
-        }
-    }
-finish:
-#undef RACC5_EPILOGUE
-#undef RACC5_LOAD
-    if (STATS && lane == 0) {
-        atomicAdd(a.stats + 0, (unsigned long long)stInner); atomicAdd(a.stats + 1, (unsigned long long)stInnerLanes);
-        atomicAdd(a.stats + 2, (unsigned long long)stLeaf);  atomicAdd(a.stats + 3, (unsigned long long)stLeafLanes);
-        atomicAdd(a.stats + 4, (unsigned long long)stRefill); atomicAdd(a.stats + 5, (unsigned long long)stLoaded);
-        atomicAdd(a.stats + 6, (unsigned long long)stDeq);   atomicAdd(a.stats + 7, 1ull);
-        atomicAdd(a.stats + 13, (unsigned long long)(__builtin_readcyclecounter() - cyStart));
-        atomicAdd(a.stats + 14, (unsigned long long)stDonations); atomicAdd(a.stats + 15, (unsigned long long)stFallbacks);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t prev = atomicInc(a.cursor + 1, gridDim.x - 1);
-        if (prev == gridDim.x - 1) atomicExch(a.cursor, 0u);
-    }
-}
-
 // ------------------------------------------------------------------------------------------ host side
 
 // ================================================================================================ V3
@@ -1761,8 +1373,6 @@ const Variant kVariants[] = {
     {256, 26, 0, traverseKernelV2<256, 26, false, false, false, false, false, false, true>, true, true}, // 28: variant 22 + touch loads of both children in thin waves
     {256, 26, 0, traverseKernelV4<256, 13, false>, false, true, 2},   // 29: V4, two ray slots per lane, 13 LDS levels each + spill
     {256, 26, 0, traverseKernelV4<256, 13, true>, false, true, 2},    // 30: variant 29 + statistics (debug)
-    {256, 26, 0, traverseKernelV5<256, 26, false>, true, true},       // 31: V5 = V2 + ray splitting in the drain (26 LDS levels, no spill path)
-    {256, 26, 0, traverseKernelV5<256, 26, true>, true, true},        // 32: variant 31 + statistics ([14] donations, [15] fallbacks)
 };
 constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kSoaVariant = 27;
@@ -1822,7 +1432,6 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.regroup = optOr(ctx->opts.regroup_period, 8u);
     a.thinReps = optOr(ctx->opts.thin_reps, 8u);
     a.innerReps = optOr(ctx->opts.inner_reps, 3u);
-    a.splitActive = optOr(ctx->opts.reserved[0], 16u); a.splitAge = optOr(ctx->opts.reserved[1], 48u); a.splitBudget = optOr(ctx->opts.reserved[2], 2u);
     a.stats = reinterpret_cast<unsigned long long*>(lane.cursor + 8);
     hipLaunchKernelGGL(v.kernel, dim3(blocks), dim3(v.block), 0, stream, a);
     HIP_TRY(hipGetLastError(), "launch traverseKernel");

@@ -236,14 +236,13 @@ class DeviceBuffer:
 class Context:
     """≙ racc::Context for the GPU intersect path; one per (process, GPU)."""
 
-    def __init__(self, device=0, lanes=0, waves_per_simd=0, refill_min=0, leaf_min=0, chunk=0, kernel_variant=0, tail_active=0, regroup_period=0, thin_reps=0, inner_reps=0, _r0=0, _r1=0, _r2=0):
+    def __init__(self, device=0, lanes=0, waves_per_simd=0, refill_min=0, leaf_min=0, chunk=0, kernel_variant=0, tail_active=0, regroup_period=0, thin_reps=0, inner_reps=0):
         lib = load_library()
         o = Options()
         o.struct_size = C.sizeof(Options)
         o.lanes, o.waves_per_simd, o.refill_min, o.leaf_min, o.chunk, o.kernel_variant = lanes, waves_per_simd, refill_min, leaf_min, chunk, kernel_variant
         o.tail_active, o.regroup_period, o.thin_reps = tail_active, regroup_period, thin_reps
         o.inner_reps = inner_reps
-        o.reserved[0], o.reserved[1], o.reserved[2] = _r0, _r1, _r2      # experimental knobs of the V5 kernel
         h = C.c_void_p()
         _check(lib.racc_hip_create(device, C.byref(o), C.byref(h)))
         self._h = h
