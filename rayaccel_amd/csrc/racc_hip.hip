@@ -1425,6 +1425,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.spill = lane.spill;
     a.spillStride = gridThreads;
     a.chunk = optOr(ctx->opts.chunk, 64u * uint32_t(v.slots));
+    if (a.chunk > 65536u) a.chunk = 65536u;      // grid waves x chunk (the statically assigned first chunks) must stay far below 2^32
     a.refillMin = optOr(ctx->opts.refill_min, 32u);
     a.leafMin = optOr(ctx->opts.leaf_min, 12u);
     a.maxIters = 1u << 24;

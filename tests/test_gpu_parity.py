@@ -132,7 +132,7 @@ def test_launch_options_do_not_change_results(small_scene, small_host, small):
     for opt in (dict(waves_per_simd=1, refill_min=1, leaf_min=1, chunk=1), dict(waves_per_simd=8, refill_min=64, leaf_min=64, chunk=4096),
                 dict(waves_per_simd=3, refill_min=20, leaf_min=7, chunk=100), dict(lanes=1, chunk=64),
                 *[dict(kernel_variant=v) for v in range(1, 31)], dict(kernel_variant=18, regroup_period=3), dict(tail_active=65),
-                dict(thin_reps=1, inner_reps=1), dict(thin_reps=3, tail_active=40, inner_reps=2), dict(thin_reps=64, tail_active=64), dict(inner_reps=16)):
+                dict(chunk=1 << 30), dict(thin_reps=1, inner_reps=1), dict(thin_reps=3, tail_active=40, inner_reps=2), dict(thin_reps=64, tail_active=64), dict(inner_reps=16)):
         with ra.Context(device=0, **opt) as ctx:
             scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
             env = ctx.create_environment(small_scene["env"])
