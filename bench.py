@@ -180,6 +180,20 @@ def main():
             ctx.intersect(scene, env, bounce, res_host)
         extras["host_buffers_pcie_inclusive_mrays_per_s"] = round(3 * n / (time.perf_counter() - t1) / 1e6, 1)
 
+        # Batch-size scaling of the traversal kernel (same diffuse rays, 8 sample sets): T(N) = fixed + per-ray cost.
+        if world == 1 and full:
+            many = np.concatenate([bounce] + [synth.diffuse_bounce_rays(sc, primary, primary_hits, RAYS_PER_BATCH, first_sample=k) for k in range(1, 8)])
+            d_many = torch.from_numpy(many.view(np.float32).reshape(len(many), 8).copy()).cuda()
+            d_many_out = torch.zeros((len(many), 4), dtype=torch.float32, device="cuda")
+            scaling = {}
+            for nn in (1 << 16, 1 << 18, 1 << 20, 1 << 22, 1 << 23):
+                ctx.intersect_device_timed(scene, env, d_many.data_ptr(), d_many_out.data_ptr(), nn, 2)
+                scaling[str(nn)] = round(float(np.median(ctx.intersect_device_timed(scene, env, d_many.data_ptr(), d_many_out.data_ptr(), nn, 7))), 4)
+            slope = (scaling[str(1 << 23)] - scaling[str(1 << 20)]) / 7.0          # ms per 2^20 rays
+            extras["batch_scaling"] = {"kernel_ms_by_rays": scaling, "steady_state_mrays_per_s": round((1 << 20) / slope / 1e3, 1),
+                                       "fixed_ms": round(scaling[str(1 << 20)] - slope, 4)}
+            del d_many, d_many_out
+
         # BASELINE configs[4]: the path tracer, 1920x1080, end to end on this GPU.  Device-resident consumer (generation and
         # shading kernels around racc_hip_intersect_device) at 64 spp; the reference-shaped consumer (spawn/shade callbacks on
         # host threads through racc::render, PCIe both ways) at 8 spp.  Both render the same image (tests/test_gpu_pathtracer.py).
