@@ -284,3 +284,12 @@ def test_pinned_host_block(gpu_ctx, small):
     got = np.frombuffer((C.c_char * (4096 * 16)).from_address(base + 4096 * 32), ra.RESULT_DTYPE).copy()
     assert lib.racc_hip_unregister_host(gpu_ctx._h, C.c_void_p(base)) == 0
     assert_bit_exact(got, orc.traverse(small["blobs"], rays, env=small["sc"]["env"]), "pinned block")
+
+
+def test_soak_random_options_sizes_and_lanes():
+    """tools/gpu_fuzz.py: random launch options, kernel variants, batch sizes (1 .. 600k) and 1-4 concurrent lanes with
+    back-to-back launches of different sizes on each, every result checked against the oracle."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_fuzz.py"), "16", "11"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

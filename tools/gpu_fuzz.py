@@ -1,0 +1,52 @@
+"""Soak test: random batch sizes / launch options / kernel variants / lanes against the oracle, bit for bit.
+   python tools/gpu_fuzz.py [rounds] [seed]"""
+import os, sys, threading
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import rayaccel_amd as ra
+from rayaccel_amd import synth
+from oracle import oracle as orc
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from helpers import assert_bit_exact        # hits bit for bit, miss colours (acosf: libm vs ocml) to 1e-5
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+sc = synth.battlefield_synth(grid=160, boxes=900, quads=4000)
+host = ra.HostScene(sc["vertices"], sc["indices"])
+blobs = host.blobs()
+prim, _ = synth.primary_rays(sc["camera"], 512, 512)
+ref_prim = orc.traverse(blobs, prim, env=sc["env"], threads=8)
+pool = np.concatenate([prim] + [synth.diffuse_bounce_rays(sc, prim, ref_prim, 1 << 18, first_sample=s) for s in range(2)])
+pool = pool[rng.permutation(len(pool))]
+ref_pool = orc.traverse(blobs, pool, env=sc["env"], threads=8)
+bad = 0
+for rnd in range(rounds):
+    opt = dict(kernel_variant=int(rng.choice([0, 0, 0, 22, 23, 24, 17, 11, 1])), lanes=int(rng.integers(1, 5)))
+    if rng.random() < 0.6:
+        opt.update(waves_per_simd=int(rng.integers(1, 9)), refill_min=int(rng.integers(1, 65)), leaf_min=int(rng.integers(1, 65)),
+                   chunk=int(rng.choice([1, 7, 32, 64, 100, 128, 1000])), tail_active=int(rng.integers(1, 70)),
+                   thin_reps=int(rng.integers(1, 20)), inner_reps=int(rng.integers(1, 9)))
+    with ra.Context(device=0, **opt) as ctx:
+        scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
+        env = ctx.create_environment(sc["env"])
+        errs = []
+
+        def work(lane, seed):
+            r2 = np.random.default_rng(seed)
+            for _ in range(4):                                      # back-to-back launches of different sizes on one lane
+                n = int(r2.choice([1, 2, 63, 64, 65, 255, 4097, int(r2.integers(1, 1 << 14)), int(r2.integers(1, len(pool) - 1))]))
+                off = int(r2.integers(0, len(pool) - n + 1))
+                got = ctx.intersect(scene, env, np.ascontiguousarray(pool[off:off + n]), lane=lane)
+                try:
+                    assert_bit_exact(got, ref_pool[off:off + n])
+                except AssertionError as e:
+                    errs.append((lane, n, off, str(e)[:120]))
+        ts = [threading.Thread(target=work, args=(l, int(rng.integers(1 << 30)))) for l in range(opt["lanes"])]
+        for t in ts: t.start()
+        for t in ts: t.join()
+        if errs:
+            bad += 1
+            print("MISMATCH", opt, errs[:3], flush=True)
+        scene.destroy(); env.destroy()
+print("fuzz: %d rounds, %d with mismatches" % (rounds, bad))
+sys.exit(1 if bad else 0)
