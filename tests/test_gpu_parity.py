@@ -1,6 +1,7 @@
 """GPU parity tests proper: the HIP path, called through the C-ABI, against the oracle on the same
 seeded inputs.  Bar: primId bit-exact; t/u/v bit-exact as well (same IEEE expression tree on both sides;
 north_star only asks for 1e-4 rel); miss colours within 1e-5 (acosf differs between libm and ocml)."""
+import os
 import threading
 
 import numpy as np
