@@ -14,13 +14,10 @@
 //     — unlike the reference's unchecked stack[64] it cannot overflow;
 //   * hit epilogues (remap gather + barycentric rotation) are batched into the refill step; miss radiance is evaluated by
 //     a second, streaming kernel (envShadeKernel).
-// Four generations live in this file and are selectable through racc_hip_options::kernel_variant:
-//   traverseKernel    V1, the first correct kernel, also with an optional LDS cache of the top of the tree;
-//   traverseKernelV2  the shipped one: V1 + thin-wave (drain) policy, lazy epilogues, deferred miss shading, static first
-//                     chunk, while-while inner repeats;
-//   traverseKernelV3  experiment: workgroup-wide regrouping of rays by phase through LDS (higher lane utilisation,
-//                     lost to its barriers);
-//   traverseKernelV4  experiment: two rays per lane (86 % lane utilisation, paid back in selects and registers).
+// traverseKernelV2 below is the shipped kernel (thin-wave drain policy, lazy epilogues, deferred miss shading, static
+// first chunk, while-while inner repeats).  Three other generations — V1 (the first correct kernel, optional LDS cache of
+// the top of the tree), V3 (workgroup-wide regrouping through LDS) and V4 (two rays per lane) — live in
+// racc_kernels_experimental.inc and stay selectable through racc_hip_options::kernel_variant.
 // Arithmetic is IEEE binary32 with explicit fmaf only (built with -ffp-contract=off, no fast-math), the same evaluation
 // order as oracle/racc_oracle.c, so primId/t/u/v are bit-identical to the CPU restatement for every finite ray.  The
 // traversal ORDER is the reference's (nearer child first, far child pushed only if both hit, pairs of a leaf in order),
@@ -197,210 +194,6 @@ __device__ __forceinline__ float4 envSample(const float4* __restrict__ env, uint
 
 __device__ __forceinline__ uint32_t laneRank(uint64_t mask) {   // # set bits below this lane: prefix sum of the ballot
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
-}
-
-// BLOCK threads per workgroup; LDS_LEVELS stack levels per ray in LDS; CACHE_NODES top-of-tree nodes in LDS.
-template <int BLOCK, int LDS_LEVELS, int CACHE_NODES, bool STATS = false>
-__global__ void __launch_bounds__(BLOCK) traverseKernel(const TraverseArgs a) {
-    // One LDS object: [node cache: CACHE_NODES x 64 B, XOR-swizzled][stack: LDS_LEVELS x BLOCK words].
-    __shared__ __attribute__((aligned(16))) uint32_t lds[CACHE_NODES * 16 + LDS_LEVELS * BLOCK];
-    constexpr int kBlock = BLOCK;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    uint32_t* const myLds = lds + CACHE_NODES * 16 + tid;                    // level stride BLOCK: bank = tid % 32 at every level
-    uint32_t* const mySpill = a.spill + (blockIdx.x * kBlock + tid);         // level stride a.spillStride
-    const float4* const ldsNodes = reinterpret_cast<const float4*>(lds);
-
-    if (CACHE_NODES > 0) {
-        // Stage the hottest nodes once per workgroup.  float4 #q of node n lives at slot q ^ ((n >> 2) & 3) of the
-        // node's 64 B row, so a 16-lane ds_read_b128 group reading q of random nodes spreads over all 16 slot
-        // positions of the 256 B bank row instead of 4.
-        float4* w = reinterpret_cast<float4*>(lds);
-        for (uint32_t i = tid; i < a.cacheCount * 4u; i += BLOCK) {
-            const uint32_t n = i >> 2, q = i & 3u;
-            w[n * 4u + (q ^ ((n >> 2) & 3u))] = a.nodes[i];
-        }
-        __syncthreads();
-    }
-
-    LaneRay r;
-    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = 0.0f;
-    r.ix = r.iy = r.iz = r.ex = r.ey = r.ez = 0.0f;
-    r.tNear = r.tFar = 0.0f; r.hitIndex = -1; r.hitU = r.hitV = 0.0f;
-    int rayIdx = -1;            // ray owned by this lane, -1 = none
-    uint32_t node = 0;          // bit31: inner ref | >= kLeafBase: leaf with pairs pending | else: no work
-    uint32_t sp = 0;
-    uint32_t wBeg = 0, wEnd = 0;        // wave's private chunk of the batch (wave-uniform)
-    bool exhausted = false;             // wave-uniform: the global cursor ran past the batch
-    uint32_t stInner = 0, stInnerLanes = 0, stLeaf = 0, stLeafLanes = 0, stRefill = 0, stLoaded = 0, stDeq = 0;
-    unsigned long long cyInner = 0, cyInnerLoad = 0, cyLeaf = 0, cyLeafLoad = 0, cyRefill = 0, cyStart = 0;
-    if (STATS) cyStart = __builtin_readcyclecounter();
-
-    for (uint32_t iter = 0;; ++iter) {
-        if (iter >= a.maxIters) {       // bounded spin: never hang the GPU on a corrupt scene
-            if (lane == 0) atomicAdd(a.cursor + 2, 1u);
-            break;
-        }
-        unsigned long long cyTop = 0;
-        if (STATS) cyTop = __builtin_readcyclecounter();
-        const uint64_t innerMask = __ballot(int(node) < 0);
-        const uint64_t idleMask = __ballot(node < kLeafBase);
-        const uint32_t nInner = __popcll(innerMask);
-        const uint32_t nIdle = __popcll(idleMask);
-        const uint32_t nLeaf = 64u - nInner - nIdle;
-        const bool noWork = (nInner | nLeaf) == 0u;
-
-        if (noWork || (nIdle >= a.refillMin && !(exhausted && __ballot(rayIdx >= 0 && node < kLeafBase) == 0ull))) {
-            // ---------------- epilogue of finished rays (Kernels.h:213-241), batched ----------------
-            if (rayIdx >= 0 && node < kLeafBase) {
-                float4 out;
-                if (r.hitIndex < 0) {
-                    out = envSample(a.env, a.envW, a.envH, r.dx, r.dy, r.dz);
-                } else {
-                    uint32_t m = a.remap[r.hitIndex];
-                    const uint32_t edge = m >> 30;
-                    m &= 0x3FFFFFFFu;
-                    const float bx = r.hitU, by = r.hitV, bz = 1.0f - r.hitU - r.hitV;
-                    float u = bx, v = by;
-                    if (edge == 1u) { u = bz; v = bx; } else if (edge == 2u) { u = by; v = bz; }
-                    out = make_float4(__uint_as_float(m), r.tFar, u, v);
-                }
-                a.results[rayIdx] = out;
-                rayIdx = -1;
-            }
-            // ---------------- refill idle lanes from the wave's chunk ----------------
-            const uint64_t emptyMask = __ballot(rayIdx < 0);
-            const uint32_t need = __popcll(emptyMask);
-            if (STATS) ++stRefill;
-            if (wBeg == wEnd && !exhausted) {
-                if (STATS) ++stDeq;
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(a.cursor, a.chunk);
-                b = __builtin_amdgcn_readfirstlane(b);
-                wBeg = min(b, a.count);
-                wEnd = min(b + a.chunk, a.count);
-                exhausted = (b >= a.count) || (b + a.chunk < b);
-            }
-            const uint32_t take = min(need, wEnd - wBeg);
-            const uint32_t rank = laneRank(emptyMask);
-            if (rayIdx < 0 && rank < take) {
-                const uint32_t idx = wBeg + rank;
-                const float4 q0 = a.rays[size_t(idx) * 2 + 0];
-                const float4 q1 = a.rays[size_t(idx) * 2 + 1];
-                const bool valid = isfinite(q0.x) && isfinite(q0.y) && isfinite(q0.z) && isfinite(q0.w) &&
-                                   isfinite(q1.x) && isfinite(q1.y) && isfinite(q1.z) && !isnan(q1.w);
-                if (!valid) {   // defined as a miss with rgb = 0 (the reference leaves this undefined)
-                    a.results[idx] = make_float4(__uint_as_float(kInvalidTriangle), 0.0f, 0.0f, 0.0f);
-                } else {
-                    const float eps = 1e-10f;   // Kernels.h:149-157
-                    r.ox = q0.x; r.oy = q0.y; r.oz = q0.z; r.tNear = q0.w;
-                    r.dx = (fabsf(q1.x) < eps) ? copysignf(eps, q1.x) : q1.x;
-                    r.dy = (fabsf(q1.y) < eps) ? copysignf(eps, q1.y) : q1.y;
-                    r.dz = (fabsf(q1.z) < eps) ? copysignf(eps, q1.z) : q1.z;
-                    r.tFar = q1.w;
-                    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;    // Kernels.h:159-160
-                    r.ex = -r.ox * r.ix; r.ey = -r.oy * r.iy; r.ez = -r.oz * r.iz;
-                    r.hitIndex = -1; r.hitU = 0.0f; r.hitV = 0.0f;
-                    rayIdx = int(idx);
-                    node = 0x80000000u;     // root is always inner node 0 (Kernels.h:164)
-                    sp = 0;
-                }
-            }
-            wBeg += take;
-            if (STATS) { stLoaded += take; cyRefill += __builtin_readcyclecounter() - cyTop; }
-            if (exhausted && wBeg == wEnd && __ballot(rayIdx >= 0) == 0ull) break;
-            continue;
-        }
-
-        if (nLeaf >= a.leafMin || nInner == 0u) {
-            // ---------------- leaf step: one triangle pair per lane (Kernels.h:200-205) ----------------
-            if (STATS) { ++stLeaf; stLeafLanes += nLeaf; }
-            if (int(node) >= int(kLeafBase)) {
-                const uint32_t cur = node & 0xFFFFFFu;
-                const uint32_t cnt = node >> 24;
-                if (STATS) {   // time the pair fetch alone (perturbs the schedule; debug variant only)
-                    const unsigned long long c0 = __builtin_readcyclecounter();
-                    const float4 probe = a.pairs[cur * 3u + 2u];
-                    asm volatile("s_waitcnt vmcnt(0)" :: "v"(probe.x) : "memory");
-                    cyLeafLoad += __builtin_readcyclecounter() - c0;
-                }
-                r.tFar = pairIntersect(a.pairs, cur, r);
-                if (cnt > 1u) {
-                    node = ((cnt - 1u) << 24) | (cur + 1u);
-                } else if (sp == 0u) {
-                    node = 0u;
-                } else {
-                    --sp;
-                    node = myLds[min(sp, uint32_t(LDS_LEVELS - 1)) * kBlock];
-                    if (sp >= uint32_t(LDS_LEVELS)) node = mySpill[size_t(sp - LDS_LEVELS) * a.spillStride];
-                }
-            }
-            if (STATS) cyLeaf += __builtin_readcyclecounter() - cyTop;
-        } else {
-            // ---------------- inner step: two slab tests, descend nearer, push farther (Kernels.h:170-199) ----------------
-            if (STATS) { ++stInner; stInnerLanes += nInner; }
-            if (int(node) < 0) {
-                const uint32_t ni = node & 0x7FFFFFFFu;
-                uint2 kids;
-                float4 d1, d2, d3;
-                if (CACHE_NODES > 0 && ni < a.cacheCount) {           // top of the tree: LDS, off the vector-memory path
-                    const uint32_t sw = (ni >> 2) & 3u;
-                    const float4* lp = ldsNodes + ni * 4u;
-                    const float4 d0 = lp[sw];
-                    kids = make_uint2(__float_as_uint(d0.x), __float_as_uint(d0.y));
-                    d1 = lp[1u ^ sw]; d2 = lp[2u ^ sw]; d3 = lp[3u ^ sw];
-                    asm volatile("" ::: "memory");   // keep these ds_read_b128: without it the two arms are merged into flat loads
-                } else {
-                    const float4* np = a.nodes + size_t(ni) * 4;
-                    unsigned long long c0 = 0;
-                    if (STATS) c0 = __builtin_readcyclecounter();
-                    kids = *reinterpret_cast<const uint2*>(np);
-                    d1 = np[1]; d2 = np[2]; d3 = np[3];
-                    asm volatile("" :: "v"(kids.x), "v"(kids.y) : "memory");   // keep the child-ref load up here, in flight with the boxes
-                    if (STATS) {
-                        asm volatile("s_waitcnt vmcnt(0)" :: "v"(d3.w), "v"(d1.x), "v"(d2.x), "v"(kids.x) : "memory");
-                        cyInnerLoad += __builtin_readcyclecounter() - c0;
-                    }
-                }
-                const float tRay = r.tFar;
-                float tFirst, tLast;
-                slabPair(d1, d2, d3, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tNear, tRay, tFirst, tLast);
-                const float firstDiff = tRay - tFirst, lastDiff = tRay - tLast;
-                if (firstDiff + lastDiff != 0.0f) {
-                    const bool lastNearer = tLast < tFirst;      // signbit(tLast - tFirst), Kernels.h:193
-                    if (tFirst != tRay && tLast != tRay) {   // == (fmax(tFirst,tLast) != tRay): both are <= tRay (Kernels.h:194)
-                        const uint32_t far = lastNearer ? kids.x : kids.y;
-                        if (sp < uint32_t(LDS_LEVELS)) myLds[sp * kBlock] = far; else mySpill[size_t(sp - LDS_LEVELS) * a.spillStride] = far;
-                        ++sp;
-                    }
-                    node = lastNearer ? kids.y : kids.x;
-                } else if (sp == 0u) {
-                    node = 0u;
-                } else {
-                    --sp;
-                    node = myLds[min(sp, uint32_t(LDS_LEVELS - 1)) * kBlock];
-                    if (sp >= uint32_t(LDS_LEVELS)) node = mySpill[size_t(sp - LDS_LEVELS) * a.spillStride];
-                }
-            }
-            if (STATS) cyInner += __builtin_readcyclecounter() - cyTop;
-        }
-    }
-
-    if (STATS && lane == 0) {
-        atomicAdd(a.stats + 0, (unsigned long long)stInner); atomicAdd(a.stats + 1, (unsigned long long)stInnerLanes);
-        atomicAdd(a.stats + 2, (unsigned long long)stLeaf);  atomicAdd(a.stats + 3, (unsigned long long)stLeafLanes);
-        atomicAdd(a.stats + 4, (unsigned long long)stRefill); atomicAdd(a.stats + 5, (unsigned long long)stLoaded);
-        atomicAdd(a.stats + 6, (unsigned long long)stDeq);   atomicAdd(a.stats + 7, 1ull);
-        atomicAdd(a.stats + 8, cyInner); atomicAdd(a.stats + 9, cyInnerLoad); atomicAdd(a.stats + 10, cyLeaf);
-        atomicAdd(a.stats + 11, cyLeafLoad); atomicAdd(a.stats + 12, cyRefill);
-        atomicAdd(a.stats + 13, (unsigned long long)(__builtin_readcyclecounter() - cyStart));
-    }
-    // The last block to leave re-arms the cursor for the next launch on this lane (no host memset needed).
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t prev = atomicInc(a.cursor + 1, gridDim.x - 1);
-        if (prev == gridDim.x - 1) atomicExch(a.cursor, 0u);
-    }
 }
 
 // ================================================================================================ V2
@@ -697,486 +490,9 @@ __global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) 
     }
 }
 
-// ================================================================================================ V4
-// Two rays per lane.  The VALU is the bound (SQ_INSTS_VALU x 4 cycles fill ~80 % of the SIMD cycles in steady state) and
-// a third of the lanes idle in every inner step: they sit at a leaf waiting for the vote, or wait for the next refill.
-// Here every lane owns TWO ray slots (A, B), each with its own stack column, and takes part in a step if EITHER slot holds
-// the right kind of work; the state of the chosen slot is selected into the step's operands with v_cndmask (~16 extra
-// VALU per inner step, ~25 per leaf step).  The CPU model (oracle/wave_sim.c) predicts 64.8 + 9.1 scheduling iterations
-// per 64 rays instead of 80.5 + 16.2.  A ray's own sequence of steps is untouched: results stay bit-identical.
-//   LDS: [level][slot][thread]; the traversal stack rarely exceeds 8 entries (0.007 % of the rays pass 12 on the bench
-//   batch), so each slot keeps LDS_LEVELS = 13 levels in LDS (26 KiB per workgroup, as V2) and spills above that.
-struct RaySlot {
-    float ox, oy, oz, dx, dy, dz, ix, iy, iz, ex, ey, ez, tNear, tFar;
-    int hitIndex;
-    float hitU, hitV;
-    uint32_t rayIdx, node, sp;
-};
-
-template <int BLOCK, int LDS_LEVELS, bool STATS>
-__global__ void __launch_bounds__(BLOCK) traverseKernelV4(const TraverseArgs a) {
-    __shared__ uint32_t lds[2 * LDS_LEVELS * BLOCK];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t gtid = blockIdx.x * BLOCK + tid;
-
-    RaySlot A, B;
-#define RACC4_CLEAR(S) do { S.ox = S.oy = S.oz = S.dx = S.dy = S.dz = S.ix = S.iy = S.iz = S.ex = S.ey = S.ez = 0.0f; \
-                            S.tNear = S.tFar = 0.0f; S.hitIndex = -1; S.hitU = S.hitV = 0.0f; S.rayIdx = 0; S.node = kEmpty; S.sp = 0; } while (0)
-    RACC4_CLEAR(A); RACC4_CLEAR(B);
-    uint32_t wBeg = min((blockIdx.x * uint32_t(BLOCK / 64) + uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6)))) * a.chunk, a.count);
-    uint32_t wEnd = min(wBeg + a.chunk, a.count);
-    bool exhausted = false;
-    uint32_t stInner = 0, stInnerLanes = 0, stLeaf = 0, stLeafLanes = 0, stRefill = 0, stLoaded = 0, stDeq = 0;
-    unsigned long long cyStart = 0;
-    if (STATS) cyStart = __builtin_readcyclecounter();
-
-    // stack entry (level, slot) of this thread
-#define RACC4_LDS(level, slot) lds[((level) * 2u + (slot)) * BLOCK + tid]
-#define RACC4_SPILL(level, slot) a.spill[size_t(((level) - LDS_LEVELS) * 2u + (slot)) * a.spillStride + gtid]
-
-    for (uint32_t iter = 0;; ++iter) {
-        if (iter >= a.maxIters) {
-            if (lane == 0) atomicAdd(a.cursor + 2, 1u);
-            break;
-        }
-        const bool innerA = int(A.node) < 0, innerB = int(B.node) < 0;
-        const bool leafA = int(A.node) >= int(kLeafBase), leafB = int(B.node) >= int(kLeafBase);
-        const uint32_t nInner = __popcll(__ballot(innerA || innerB));       // lanes that can take an inner step
-        const uint32_t nLeaf = __popcll(__ballot(leafA || leafB));
-        const uint32_t idleSlots = uint32_t(__popcll(__ballot(A.node <= kDone))) + uint32_t(__popcll(__ballot(B.node <= kDone)));
-        const bool noWork = (nInner | nLeaf) == 0u;
-        bool refill = noWork;
-        if (!noWork) {
-            if (!exhausted) refill = idleSlots >= a.refillMin;
-            else refill = uint32_t(__popcll(__ballot(A.node == kDone))) + uint32_t(__popcll(__ballot(B.node == kDone))) >= a.refillMin;
-        }
-
-        if (refill) {
-            if (STATS) ++stRefill;
-            // ---------------- batched epilogue (Kernels.h:213-241), slot by slot ----------------
-#define RACC4_EPILOGUE(S)                                                                                              \
-            if (S.node == kDone) {                                                                                     \
-                float4 out;                                                                                            \
-                if (S.hitIndex < 0) {                                                                                  \
-                    out = a.env ? make_float4(__uint_as_float(kInvalidTriangle), S.dx, S.dy, S.dz)                     \
-                                : make_float4(__uint_as_float(kInvalidTriangle), 0.0f, 0.0f, 0.0f);                    \
-                } else {                                                                                               \
-                    uint32_t m = a.remap[S.hitIndex];                                                                  \
-                    const uint32_t edge = m >> 30;                                                                     \
-                    m &= 0x3FFFFFFFu;                                                                                  \
-                    const float bx = S.hitU, by = S.hitV, bz = 1.0f - S.hitU - S.hitV;                                 \
-                    float u = bx, v = by;                                                                              \
-                    if (edge == 1u) { u = bz; v = bx; } else if (edge == 2u) { u = by; v = bz; }                       \
-                    out = make_float4(__uint_as_float(m), S.tFar, u, v);                                               \
-                }                                                                                                      \
-                a.results[S.rayIdx] = out;                                                                             \
-                S.node = kEmpty;                                                                                       \
-            }
-            RACC4_EPILOGUE(A)
-            RACC4_EPILOGUE(B)
-            // ---------------- refill: empty A slots first, then empty B slots ----------------
-            const uint64_t emptyA = __ballot(A.node == kEmpty), emptyB = __ballot(B.node == kEmpty);
-            const uint32_t needA = __popcll(emptyA), need = needA + uint32_t(__popcll(emptyB));
-            if (wBeg == wEnd && !exhausted) {
-                if (STATS) ++stDeq;
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(a.cursor, a.chunk);
-                const uint32_t r = __builtin_amdgcn_readfirstlane(b);
-                b = r + gridDim.x * uint32_t(BLOCK / 64) * a.chunk;
-                if (b < r) b = 0xFFFFFFFFu;
-                exhausted = (b >= a.count) || (b + a.chunk < b);
-                wBeg = exhausted ? a.count : b;
-                wEnd = exhausted ? a.count : min(b + a.chunk, a.count);
-            }
-            const uint32_t take = min(need, wEnd - wBeg);
-            const uint32_t rankA = laneRank(emptyA), rankB = needA + laneRank(emptyB);
-#define RACC4_LOAD(S, rank)                                                                                            \
-            if (S.node == kEmpty && (rank) < take) {                                                                   \
-                const uint32_t idx = wBeg + (rank);                                                                    \
-                const float4 q0 = a.rays[size_t(idx) * 2 + 0];                                                         \
-                const float4 q1 = a.rays[size_t(idx) * 2 + 1];                                                         \
-                const bool valid = isfinite(q0.x) && isfinite(q0.y) && isfinite(q0.z) && isfinite(q0.w) &&             \
-                                   isfinite(q1.x) && isfinite(q1.y) && isfinite(q1.z) && !isnan(q1.w);                 \
-                if (!valid) {                                                                                          \
-                    a.results[idx] = make_float4(__uint_as_float(kInvalidTriangle), a.env ? __uint_as_float(0x7FC00000u) : 0.0f, 0.0f, 0.0f); \
-                } else {                                                                                               \
-                    const float eps = 1e-10f;                                                                          \
-                    S.ox = q0.x; S.oy = q0.y; S.oz = q0.z; S.tNear = q0.w;                                             \
-                    S.dx = (fabsf(q1.x) < eps) ? copysignf(eps, q1.x) : q1.x;                                          \
-                    S.dy = (fabsf(q1.y) < eps) ? copysignf(eps, q1.y) : q1.y;                                          \
-                    S.dz = (fabsf(q1.z) < eps) ? copysignf(eps, q1.z) : q1.z;                                          \
-                    S.tFar = q1.w;                                                                                     \
-                    S.ix = 1.0f / S.dx; S.iy = 1.0f / S.dy; S.iz = 1.0f / S.dz;                                        \
-                    S.ex = -S.ox * S.ix; S.ey = -S.oy * S.iy; S.ez = -S.oz * S.iz;                                     \
-                    S.hitIndex = -1; S.hitU = 0.0f; S.hitV = 0.0f;                                                     \
-                    S.rayIdx = idx;                                                                                    \
-                    S.node = 0x80000000u;                                                                              \
-                    S.sp = 0;                                                                                          \
-                }                                                                                                      \
-            }
-            RACC4_LOAD(A, rankA)
-            RACC4_LOAD(B, rankB)
-            wBeg += take;
-            if (STATS) stLoaded += take;
-            if (exhausted && wBeg == wEnd && __ballot(A.node != kEmpty || B.node != kEmpty) == 0ull) break;
-            continue;
-        }
-
-        const uint32_t nActive = __popcll(__ballot(innerA || innerB || leafA || leafB));
-        const bool doLeaf = nLeaf >= a.leafMin || nInner == 0u || nLeaf * 4u >= nActive;
-        const bool doInner = nInner != 0u && (!doLeaf || nActive <= a.tailActive);
-        if (doLeaf) {
-            // ---------------- leaf step on slot A if it waits at a leaf, else on slot B ----------------
-            if (STATS) { ++stLeaf; stLeafLanes += nLeaf; }
-            const bool la = int(A.node) >= int(kLeafBase), lb = int(B.node) >= int(kLeafBase);
-            if (la || lb) {
-                const bool useB = !la;
-                const uint32_t node = useB ? B.node : A.node;
-                LaneRay r;
-                r.ox = useB ? B.ox : A.ox; r.oy = useB ? B.oy : A.oy; r.oz = useB ? B.oz : A.oz;
-                r.dx = useB ? B.dx : A.dx; r.dy = useB ? B.dy : A.dy; r.dz = useB ? B.dz : A.dz;
-                r.ix = r.iy = r.iz = r.ex = r.ey = r.ez = 0.0f;      // unused by the pair test
-                r.tNear = useB ? B.tNear : A.tNear; r.tFar = useB ? B.tFar : A.tFar;
-                r.hitIndex = useB ? B.hitIndex : A.hitIndex; r.hitU = useB ? B.hitU : A.hitU; r.hitV = useB ? B.hitV : A.hitV;
-                const uint32_t cur = node & 0xFFFFFFu;
-                const uint32_t cnt = node >> 24;
-                const float4 t0 = a.pairs[cur * 3u], t1 = a.pairs[cur * 3u + 1u], t2 = a.pairs[cur * 3u + 2u];
-                r.tFar = pairIntersectData(t0, t1, t2, cur, r);
-                uint32_t sp = useB ? B.sp : A.sp;
-                uint32_t next;
-                if (cnt > 1u) next = ((cnt - 1u) << 24) | (cur + 1u);
-                else if (sp == 0u) next = kDone;
-                else {
-                    --sp;
-                    next = RACC4_LDS(min(sp, uint32_t(LDS_LEVELS - 1)), useB ? 1u : 0u);
-                    if (sp >= uint32_t(LDS_LEVELS)) next = RACC4_SPILL(sp, useB ? 1u : 0u);
-                }
-                if (useB) { B.tFar = r.tFar; B.hitIndex = r.hitIndex; B.hitU = r.hitU; B.hitV = r.hitV; B.node = next; B.sp = sp; }
-                else      { A.tFar = r.tFar; A.hitIndex = r.hitIndex; A.hitU = r.hitU; A.hitV = r.hitV; A.node = next; A.sp = sp; }
-            }
-        }
-        if (doInner) {
-            // ---------------- inner steps on slot A if it holds an inner node, else on slot B ----------------
-            const uint32_t reps = nActive <= a.tailActive ? a.thinReps : a.innerReps;
-            for (uint32_t rep = 0;; ++rep) {
-                const bool ia = int(A.node) < 0, ib = int(B.node) < 0;
-                if (STATS) { ++stInner; stInnerLanes += uint32_t(__popcll(__ballot(ia || ib))); }
-                if (ia || ib) {
-                    const bool useB = !ia;
-                    const uint32_t node = useB ? B.node : A.node;
-                    const float4* np = a.nodes + size_t(node & 0x7FFFFFFFu) * 4;
-                    const uint2 kids = *reinterpret_cast<const uint2*>(np);
-                    const float4 d1 = np[1], d2 = np[2], d3 = np[3];
-                    asm volatile("" :: "v"(kids.x), "v"(kids.y));
-                    const float ix = useB ? B.ix : A.ix, iy = useB ? B.iy : A.iy, iz = useB ? B.iz : A.iz;
-                    const float ex = useB ? B.ex : A.ex, ey = useB ? B.ey : A.ey, ez = useB ? B.ez : A.ez;
-                    const float tNear = useB ? B.tNear : A.tNear, tRay = useB ? B.tFar : A.tFar;
-                    uint32_t sp = useB ? B.sp : A.sp;
-                    float tFirst, tLast;
-                    slabPair(d1, d2, d3, ix, iy, iz, ex, ey, ez, tNear, tRay, tFirst, tLast);
-                    const float firstDiff = tRay - tFirst, lastDiff = tRay - tLast;
-                    uint32_t next;
-                    if (firstDiff + lastDiff != 0.0f) {
-                        const bool lastNearer = tLast < tFirst;
-                        if (tFirst != tRay && tLast != tRay) {
-                            const uint32_t far = lastNearer ? kids.x : kids.y;
-                            if (sp < uint32_t(LDS_LEVELS)) RACC4_LDS(sp, useB ? 1u : 0u) = far;
-                            else RACC4_SPILL(sp, useB ? 1u : 0u) = far;
-                            ++sp;
-                        }
-                        next = lastNearer ? kids.y : kids.x;
-                    } else if (sp == 0u) {
-                        next = kDone;
-                    } else {
-                        --sp;
-                        next = RACC4_LDS(min(sp, uint32_t(LDS_LEVELS - 1)), useB ? 1u : 0u);
-                        if (sp >= uint32_t(LDS_LEVELS)) next = RACC4_SPILL(sp, useB ? 1u : 0u);
-                    }
-                    if (useB) { B.node = next; B.sp = sp; } else { A.node = next; A.sp = sp; }
-                }
-                if (rep + 1u >= reps || __ballot(int(A.node) < 0 || int(B.node) < 0) == 0ull) break;
-            }
-        }
-    }
-#undef RACC4_CLEAR
-#undef RACC4_LDS
-#undef RACC4_SPILL
-#undef RACC4_EPILOGUE
-#undef RACC4_LOAD
-
-    if (STATS && lane == 0) {
-        atomicAdd(a.stats + 0, (unsigned long long)stInner); atomicAdd(a.stats + 1, (unsigned long long)stInnerLanes);
-        atomicAdd(a.stats + 2, (unsigned long long)stLeaf);  atomicAdd(a.stats + 3, (unsigned long long)stLeafLanes);
-        atomicAdd(a.stats + 4, (unsigned long long)stRefill); atomicAdd(a.stats + 5, (unsigned long long)stLoaded);
-        atomicAdd(a.stats + 6, (unsigned long long)stDeq);   atomicAdd(a.stats + 7, 1ull);
-        atomicAdd(a.stats + 13, (unsigned long long)(__builtin_readcyclecounter() - cyStart));
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t prev = atomicInc(a.cursor + 1, gridDim.x - 1);
-        if (prev == gridDim.x - 1) atomicExch(a.cursor, 0u);
-    }
-}
+#include "racc_kernels_experimental.inc"
 
 // ------------------------------------------------------------------------------------------ host side
-
-// ================================================================================================ V3
-// Workgroup-wide ballot/prefix-sum compaction.  V1/V2 keep a ray in the lane that loaded it, so a wave is a mix of
-// lanes that hold an inner node, lanes that wait at a leaf and lanes that wait for a refill: measured lane utilisation
-// 66 % in inner steps and 15 % in leaf steps even in steady state (profiles/).  Here the WAVES waves of a workgroup
-// re-deal their rays every `regroup` scheduling iterations: each ray is classified (inner / leaf / finished / empty
-// lane), a counting sort over the whole workgroup (wave ballots + mbcnt ranks + one 64-lane scan of the per-wave
-// counts) gives every ray a new lane so that each wave holds ONE kind of work, and the per-ray state — kept as a
-// [field][slot] structure-of-arrays record in LDS next to its [level][slot] stack — is re-read by its new lane.
-// Inner waves then run the slab-test body with ~all lanes live, the leaf wave runs the pair test with ~all lanes
-// live, finished rays get their epilogue together and empty lanes refill together.  A ray's arithmetic and the order
-// of its own steps are untouched, so results stay bit-identical to the oracle.
-//   LDS per workgroup: (LDS_LEVELS + 20 + 1) * T * 4 B  (T = 64 * WAVES): 74 KiB at T = 512 -> two workgroups per CU.
-constexpr int kRecFields = 20;   // o[3] d[3] inv[3] ood[3] tNear rayIdx | node sp tFar hitIndex hitU hitV
-
-template <int WAVES, int LDS_LEVELS, bool SPILL, bool STATS>
-__global__ void __launch_bounds__(WAVES * 64) traverseKernelV3(const TraverseArgs a) {
-    constexpr int T = WAVES * 64;
-    static_assert(WAVES <= 16, "the regroup scan keeps 4 x WAVES counters in one wave");
-    __shared__ uint32_t lds[LDS_LEVELS * T + kRecFields * T + T + 64 + 4];
-    uint32_t* const stackBase = lds;                               // [level][slot]
-    uint32_t* const rec = lds + LDS_LEVELS * T;                    // [field][slot]
-    uint32_t* const perm = rec + kRecFields * T;                   // [lane of the workgroup] -> slot
-    uint32_t* const waveCount = perm + T;                          // [kind][wave], 4 x WAVES <= 64 words
-    uint32_t* const wgFlags = waveCount + 64;                      // [0] batch exhausted
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    LaneRay r;
-    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = 0.0f;
-    r.ix = r.iy = r.iz = r.ex = r.ey = r.ez = 0.0f;
-    r.tNear = r.tFar = 0.0f; r.hitIndex = -1; r.hitU = r.hitV = 0.0f;
-    uint32_t rayIdx = 0;
-    uint32_t node = kEmpty;
-    uint32_t sp = 0;
-    uint32_t slot = tid;                 // which stack column / record this lane's ray owns; travels with the ray
-    uint32_t wBeg = 0, wEnd = 0;
-    bool exhausted = false;
-    uint32_t stInner = 0, stInnerLanes = 0, stLeaf = 0, stLeafLanes = 0, stRefill = 0, stLoaded = 0, stDeq = 0, stShuffle = 0;
-    unsigned long long cyInner = 0, cyLeaf = 0, cyRefill = 0, cyShuffle = 0, cyStart = 0;
-    if (STATS) cyStart = __builtin_readcyclecounter();
-
-    if (tid == 0) wgFlags[0] = 0u;
-    __syncthreads();
-
-#define RACC3_PUSH(val_)                                                                          \
-    do {                                                                                          \
-        const uint32_t pv_ = (val_);                                                              \
-        if (!SPILL || sp < uint32_t(LDS_LEVELS)) stackBase[sp * T + slot] = pv_;                  \
-        else a.spill[size_t(sp - LDS_LEVELS) * a.spillStride + blockIdx.x * T + slot] = pv_;      \
-        ++sp;                                                                                     \
-    } while (0)
-#define RACC3_POP_OR_DONE()                                                                       \
-    do {                                                                                          \
-        if (sp == 0u) { node = kDone; }                                                           \
-        else {                                                                                    \
-            --sp;                                                                                 \
-            node = stackBase[(SPILL ? min(sp, uint32_t(LDS_LEVELS - 1)) : sp) * T + slot];        \
-            if (SPILL && sp >= uint32_t(LDS_LEVELS))                                              \
-                node = a.spill[size_t(sp - LDS_LEVELS) * a.spillStride + blockIdx.x * T + slot];  \
-        }                                                                                         \
-    } while (0)
-
-    for (uint32_t round = 0;; ++round) {
-        if (round >= (a.maxIters >> 4)) {   // bounded: never hang the GPU (uniform across the workgroup)
-            if (tid == 0) atomicAdd(a.cursor + 2, 1u);
-            break;
-        }
-        // ------------------------------------------------ up to `regroup` scheduling iterations, wave-private
-        for (uint32_t it = 0; it < a.regroup; ++it) {
-            unsigned long long cyTop = 0;
-            if (STATS) cyTop = __builtin_readcyclecounter();
-            const uint32_t nInner = __popcll(__ballot(int(node) < 0));
-            const uint32_t nLeaf = __popcll(__ballot(int(node) >= int(kLeafBase)));
-            const bool noWork = (nInner | nLeaf) == 0u;
-            bool refill = noWork;
-            if (!noWork) {
-                if (!exhausted) refill = (64u - nInner - nLeaf) >= a.refillMin;
-                else refill = uint32_t(__popcll(__ballot(node == kDone))) >= a.refillMin;
-            }
-            if (refill) {
-                if (node == kDone) {       // ---- batched epilogue (Kernels.h:223-239; misses: see envShadeKernel)
-                    float4 out;
-                    if (r.hitIndex < 0) {
-                        out = a.env ? make_float4(__uint_as_float(kInvalidTriangle), r.dx, r.dy, r.dz)
-                                    : make_float4(__uint_as_float(kInvalidTriangle), 0.0f, 0.0f, 0.0f);
-                    } else {
-                        uint32_t m = a.remap[r.hitIndex];
-                        const uint32_t edge = m >> 30;
-                        m &= 0x3FFFFFFFu;
-                        const float bx = r.hitU, by = r.hitV, bz = 1.0f - r.hitU - r.hitV;
-                        float u = bx, v = by;
-                        if (edge == 1u) { u = bz; v = bx; } else if (edge == 2u) { u = by; v = bz; }
-                        out = make_float4(__uint_as_float(m), r.tFar, u, v);
-                    }
-                    a.results[rayIdx] = out;
-                    node = kEmpty;
-                }
-                const uint64_t emptyMask = __ballot(node == kEmpty);
-                const uint32_t need = __popcll(emptyMask);
-                if (STATS) ++stRefill;
-                if (wBeg == wEnd && !exhausted) {
-                    if (STATS) ++stDeq;
-                    uint32_t b = 0;
-                    if (lane == 0) b = atomicAdd(a.cursor, a.chunk);
-                    b = __builtin_amdgcn_readfirstlane(b);
-                    wBeg = min(b, a.count);
-                    wEnd = min(b + a.chunk, a.count);
-                    exhausted = (b >= a.count) || (b + a.chunk < b);
-                    if (exhausted && lane == 0) wgFlags[0] = 1u;
-                }
-                const uint32_t take = min(need, wEnd - wBeg);
-                const uint32_t rank = laneRank(emptyMask);
-                if (node == kEmpty && rank < take) {
-                    const uint32_t idx = wBeg + rank;
-                    const float4 q0 = a.rays[size_t(idx) * 2 + 0];
-                    const float4 q1 = a.rays[size_t(idx) * 2 + 1];
-                    const bool valid = isfinite(q0.x) && isfinite(q0.y) && isfinite(q0.z) && isfinite(q0.w) &&
-                                       isfinite(q1.x) && isfinite(q1.y) && isfinite(q1.z) && !isnan(q1.w);
-                    if (!valid) {
-                        a.results[idx] = make_float4(__uint_as_float(kInvalidTriangle), a.env ? __uint_as_float(0x7FC00000u) : 0.0f, 0.0f, 0.0f);
-                    } else {
-                        const float eps = 1e-10f;   // Kernels.h:149-157
-                        r.ox = q0.x; r.oy = q0.y; r.oz = q0.z; r.tNear = q0.w;
-                        r.dx = (fabsf(q1.x) < eps) ? copysignf(eps, q1.x) : q1.x;
-                        r.dy = (fabsf(q1.y) < eps) ? copysignf(eps, q1.y) : q1.y;
-                        r.dz = (fabsf(q1.z) < eps) ? copysignf(eps, q1.z) : q1.z;
-                        r.tFar = q1.w;
-                        r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;    // Kernels.h:159-160
-                        r.ex = -r.ox * r.ix; r.ey = -r.oy * r.iy; r.ez = -r.oz * r.iz;
-                        r.hitIndex = -1; r.hitU = 0.0f; r.hitV = 0.0f;
-                        rayIdx = idx;
-                        node = 0x80000000u;     // Kernels.h:164
-                        sp = 0;
-                        // The immutable part of the record is written once, here; regrouping re-reads it by slot.
-                        uint32_t* rp = rec + slot;
-                        rp[0 * T] = __float_as_uint(r.ox); rp[1 * T] = __float_as_uint(r.oy); rp[2 * T] = __float_as_uint(r.oz);
-                        rp[3 * T] = __float_as_uint(r.dx); rp[4 * T] = __float_as_uint(r.dy); rp[5 * T] = __float_as_uint(r.dz);
-                        rp[6 * T] = __float_as_uint(r.ix); rp[7 * T] = __float_as_uint(r.iy); rp[8 * T] = __float_as_uint(r.iz);
-                        rp[9 * T] = __float_as_uint(r.ex); rp[10 * T] = __float_as_uint(r.ey); rp[11 * T] = __float_as_uint(r.ez);
-                        rp[12 * T] = __float_as_uint(r.tNear); rp[13 * T] = rayIdx;
-                    }
-                }
-                wBeg += take;
-                if (STATS) { stLoaded += take; cyRefill += __builtin_readcyclecounter() - cyTop; }
-                if (exhausted && wBeg == wEnd && __ballot(node != kEmpty) == 0ull) break;   // this wave is dry: go regroup
-                continue;
-            }
-
-            const uint32_t nActive = nInner + nLeaf;
-            const bool thin = nActive <= a.tailActive;
-            const bool doLeaf = nLeaf >= a.leafMin || nInner == 0u || (thin && nLeaf * 4u >= nActive);
-            const bool doInner = nInner != 0u && (!doLeaf || thin);
-            if (doLeaf) {
-                if (STATS) { ++stLeaf; stLeafLanes += nLeaf; }
-                if (int(node) >= int(kLeafBase)) {      // ---- leaf step (Kernels.h:200-205 + 36-115)
-                    const uint32_t cur = node & 0xFFFFFFu;
-                    const uint32_t cnt = node >> 24;
-                    r.tFar = pairIntersectData(a.pairs[cur * 3u], a.pairs[cur * 3u + 1u], a.pairs[cur * 3u + 2u], cur, r);
-                    if (cnt > 1u) node = ((cnt - 1u) << 24) | (cur + 1u);
-                    else RACC3_POP_OR_DONE();
-                }
-                if (STATS) { cyLeaf += __builtin_readcyclecounter() - cyTop; cyTop = __builtin_readcyclecounter(); }
-            }
-            if (doInner) {
-                if (STATS) { ++stInner; stInnerLanes += nInner; }
-                if (int(node) < 0) {                    // ---- inner step (Kernels.h:170-199 + 117-135)
-                    const float4* np = a.nodes + size_t(node & 0x7FFFFFFFu) * 4;
-                    const uint2 kids = *reinterpret_cast<const uint2*>(np);
-                    const float4 d1 = np[1], d2 = np[2], d3 = np[3];
-                    asm volatile("" :: "v"(kids.x), "v"(kids.y));   // keep the child-ref load up here, in flight with the boxes
-                    const float tRay = r.tFar;
-                    float tFirst, tLast;
-                    slabPair(d1, d2, d3, r.ix, r.iy, r.iz, r.ex, r.ey, r.ez, r.tNear, tRay, tFirst, tLast);
-                    const float firstDiff = tRay - tFirst, lastDiff = tRay - tLast;
-                    if (firstDiff + lastDiff != 0.0f) {
-                        const bool lastNearer = tLast < tFirst;      // signbit(tLast - tFirst), Kernels.h:193
-                        if (tFirst != tRay && tLast != tRay) RACC3_PUSH(lastNearer ? kids.x : kids.y);
-                        node = lastNearer ? kids.y : kids.x;
-                    } else {
-                        RACC3_POP_OR_DONE();
-                    }
-                }
-                if (STATS) cyInner += __builtin_readcyclecounter() - cyTop;
-            }
-        }
-
-        // ------------------------------------------------ regroup: counting sort of the workgroup's rays by kind
-        unsigned long long cySh = 0;
-        if (STATS) { cySh = __builtin_readcyclecounter(); ++stShuffle; }
-        const uint32_t kind = (int(node) < 0) ? 0u : (node >= kLeafBase) ? 1u : (node == kDone) ? 2u : 3u;
-        const uint64_t m0 = __ballot(kind == 0u), m1 = __ballot(kind == 1u), m2 = __ballot(kind == 2u), m3 = __ballot(kind == 3u);
-        const uint64_t mine = kind == 0u ? m0 : kind == 1u ? m1 : kind == 2u ? m2 : m3;
-        const uint32_t rankInWave = laneRank(mine);
-        // No barrier is needed here: a wave only rewrites the records of slots it owns, the per-wave counters are last
-        // read before B3 of the previous regroup, and `perm` is rewritten only after B2 of this one.
-        if (lane < 4u) {
-            const uint64_t mk = lane == 0u ? m0 : lane == 1u ? m1 : lane == 2u ? m2 : m3;
-            waveCount[lane * WAVES + wave] = uint32_t(__popcll(mk));
-        }
-        {   // mutable part of the record
-            uint32_t* rp = rec + slot;
-            rp[14 * T] = node; rp[15 * T] = sp; rp[16 * T] = __float_as_uint(r.tFar);
-            rp[17 * T] = uint32_t(r.hitIndex); rp[18 * T] = __float_as_uint(r.hitU); rp[19 * T] = __float_as_uint(r.hitV);
-        }
-        __syncthreads();                                   // B1: counts and records visible
-        // One 64-lane exclusive scan of the (kind-major) counter table gives, at entry kind*WAVES + wave, the first
-        // destination lane of that wave's rays of that kind.
-        uint32_t cntHere = (lane < 4u * WAVES) ? waveCount[lane] : 0u;
-        uint32_t incl = cntHere;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d);
-            if (lane >= uint32_t(d)) incl += up;
-        }
-        const uint32_t excl = incl - cntHere;
-        const uint32_t destBase = __shfl(excl, int(kind * WAVES + wave));
-        const uint32_t liveRays = __builtin_amdgcn_readfirstlane(__shfl(excl, 3 * WAVES));   // inner + leaf + finished, whole workgroup
-        perm[destBase + rankInWave] = slot;
-        exhausted = exhausted || (wgFlags[0] != 0u);
-        __syncthreads();                                   // B2: permutation complete
-        slot = perm[tid];
-        {
-            const uint32_t* rp = rec + slot;
-            r.ox = __uint_as_float(rp[0 * T]); r.oy = __uint_as_float(rp[1 * T]); r.oz = __uint_as_float(rp[2 * T]);
-            r.dx = __uint_as_float(rp[3 * T]); r.dy = __uint_as_float(rp[4 * T]); r.dz = __uint_as_float(rp[5 * T]);
-            r.ix = __uint_as_float(rp[6 * T]); r.iy = __uint_as_float(rp[7 * T]); r.iz = __uint_as_float(rp[8 * T]);
-            r.ex = __uint_as_float(rp[9 * T]); r.ey = __uint_as_float(rp[10 * T]); r.ez = __uint_as_float(rp[11 * T]);
-            r.tNear = __uint_as_float(rp[12 * T]); rayIdx = rp[13 * T];
-            node = rp[14 * T]; sp = rp[15 * T]; r.tFar = __uint_as_float(rp[16 * T]);
-            r.hitIndex = int(rp[17 * T]); r.hitU = __uint_as_float(rp[18 * T]); r.hitV = __uint_as_float(rp[19 * T]);
-        }
-        if (STATS) cyShuffle += __builtin_readcyclecounter() - cySh;
-        // Workgroup-uniform exit: `exhausted` was re-read from the shared flag between B1 and B2 (no wave can write it
-        // there), liveRays comes from the shared counters.  A wave that still owns undealt rays of its chunk always holds
-        // live rays (it refills whenever it has nothing else to do), so liveRays == 0 also means no chunk is pending.
-        if (liveRays == 0u && exhausted) break;
-    }
-#undef RACC3_PUSH
-#undef RACC3_POP_OR_DONE
-
-    if (STATS && lane == 0) {
-        atomicAdd(a.stats + 0, (unsigned long long)stInner); atomicAdd(a.stats + 1, (unsigned long long)stInnerLanes);
-        atomicAdd(a.stats + 2, (unsigned long long)stLeaf);  atomicAdd(a.stats + 3, (unsigned long long)stLeafLanes);
-        atomicAdd(a.stats + 4, (unsigned long long)stRefill); atomicAdd(a.stats + 5, (unsigned long long)stLoaded);
-        atomicAdd(a.stats + 6, (unsigned long long)stDeq);   atomicAdd(a.stats + 7, 1ull);
-        atomicAdd(a.stats + 8, cyInner); atomicAdd(a.stats + 10, cyLeaf); atomicAdd(a.stats + 12, cyRefill);
-        atomicAdd(a.stats + 13, (unsigned long long)(__builtin_readcyclecounter() - cyStart));
-        atomicAdd(a.stats + 14, cyShuffle); atomicAdd(a.stats + 15, (unsigned long long)stShuffle);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t prev = atomicInc(a.cursor + 1, gridDim.x - 1);
-        if (prev == gridDim.x - 1) atomicExch(a.cursor, 0u);
-    }
-}
 
 // Second (tiny, streaming) kernel of the V2 path: every miss record holds the ray direction; replace it by the
 // probe-image radiance (Kernels.h:213-222).  16 B read per ray, 16 B written per miss.
