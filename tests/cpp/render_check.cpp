@@ -139,6 +139,9 @@ int main(int argc, char** argv) {
     racc::Configuration cfg = racc::defaultConfiguration(gpu);
     if (const char* t = std::getenv("RACC_CPU_THREADS")) cfg.cpuThreads = unsigned(std::atoi(t));
     if (const char* t = std::getenv("RACC_BATCH")) cfg.rayStreamBatchSize = unsigned(std::atoi(t));
+    if (const char* t = std::getenv("RACC_IN_FLIGHT")) cfg.maxRaysInFlight = unsigned(std::atoi(t));
+    if (const char* t = std::getenv("RACC_GPU_THREADS")) cfg.gpuSubmissionThreads = unsigned(std::atoi(t));
+    if (const char* t = std::getenv("RACC_SHADE_BATCH")) cfg.cpuShadeBatch = unsigned(std::atoi(t));
     racc::Context* ctx = racc::createContext(cfg);
     if (!ctx) return 3;
     app.info = racc::info(ctx);

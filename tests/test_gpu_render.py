@@ -35,7 +35,10 @@ def _run(tmp_path, sc, w, h, depth, frames=1, env=None):
     return info, recs
 
 
-@pytest.mark.parametrize("cfg", [dict(), dict(RACC_CPU_THREADS="3", RACC_BATCH="20000")])
+@pytest.mark.parametrize("cfg", [dict(), dict(RACC_CPU_THREADS="3", RACC_BATCH="20000"),
+                                 # starved scheduler: tiny streams, few rays in flight, one lane, small shade batches
+                                 dict(RACC_CPU_THREADS="5", RACC_BATCH="1024", RACC_IN_FLIGHT="40000", RACC_GPU_THREADS="1", RACC_SHADE_BATCH="300"),
+                                 dict(RACC_CPU_THREADS="1", RACC_BATCH="16384", RACC_IN_FLIGHT="16384", RACC_GPU_THREADS="4")])
 def test_render_matches_oracle(tmp_path, small_scene, small_host, cfg):
     assert ra.RAY_DTYPE.itemsize == 32
     info, recs = _run(str(tmp_path), small_scene, 512, 384, 3, frames=2, env=cfg)
