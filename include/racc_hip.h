@@ -125,7 +125,8 @@ int racc_hip_wait(racc_hip_ctx* ctx, uint32_t lane);
  * <=27k-ray stream (RayAccelerator.cpp:369-404); 27k rays occupy 5 % of the 524,288 lanes a MI355X keeps
  * resident and every launch pays the latency of its longest ray, so the scheduler (racc::render) hands over
  * everything that is ready.  rays[i]/results[i] are host arrays of counts[i] records; results land in place
- * and in order per stream.  Blocking. */
+ * and in order per stream.  Blocking.  When the arrays are page-locked (racc_hip_register_*) and the launch has
+ * >= 512k rays it is cut into 256k-ray slices whose PCIe copies run beside the neighbouring slices' kernels. */
 int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
                                uint32_t n_streams, const void* const* rays, void* const* results,
                                const uint32_t* counts, uint32_t lane);

@@ -287,6 +287,30 @@ def test_pinned_host_block(gpu_ctx, small):
     assert_bit_exact(got, orc.traverse(small["blobs"], rays, env=small["sc"]["env"]), "pinned block")
 
 
+def test_sliced_host_path_with_page_locked_streams(gpu_ctx, full):
+    """Page-locked host arrays and >= 512k rays take the pipelined path (copies of one slice beside the kernel of another);
+    slice boundaries fall inside the ray streams.  Same results as the plain path, stream by stream, bit for bit."""
+    lib = ra.load_library()
+    prim = full["primary"]
+    sizes = (300001, 1, 400000, 77)                              # 700079 rays -> 3 slices of ~233k
+    offs = np.cumsum((0,) + sizes)
+    streams = [np.ascontiguousarray(prim[offs[i]:offs[i + 1]]) for i in range(len(sizes))]
+    plain = gpu_ctx.intersect_streams(full["scene"], full["env"], streams)           # pageable: unsliced
+    outs = [np.zeros(n, ra.RESULT_DTYPE) for n in sizes]
+    import ctypes as C
+    for a in streams + outs:
+        assert lib.racc_hip_register_host(gpu_ctx._h, C.c_void_p(a.ctypes.data), a.nbytes) == 0
+    n = len(sizes)
+    pr = (C.c_void_p * n)(*[a.ctypes.data for a in streams]); po = (C.c_void_p * n)(*[a.ctypes.data for a in outs]); cn = (C.c_uint32 * n)(*sizes)
+    assert lib.racc_hip_intersect_streams(gpu_ctx._h, full["scene"]._h, full["env"]._h, n, pr, po, cn, 1) == 0
+    for a in streams + outs:
+        assert lib.racc_hip_unregister_host(gpu_ctx._h, C.c_void_p(a.ctypes.data)) == 0
+    for got, want in zip(outs, plain):
+        assert got.tobytes() == want.tobytes()
+    ref = orc.traverse(full["host"].blobs(), streams[2][:50000], env=full["sc"]["env"], threads=8)
+    assert_bit_exact(outs[2][:50000], ref, "sliced path")
+
+
 def test_soak_random_options_sizes_and_lanes():
     """tools/gpu_fuzz.py: random launch options, kernel variants, batch sizes (1 .. 600k) and 1-4 concurrent lanes with
     back-to-back launches of different sizes on each, every result checked against the oracle."""
