@@ -80,3 +80,20 @@ def test_only_whole_tiles_are_rendered(scene_file):
     img, st = path_trace(scene_file, 300, 200, 0, 1)                    # TiledRenderer.cpp:20-22
     assert (st["tiles_x"], st["tiles_y"]) == (2, 1) and st["primary_rays"] == 2 * 128 * 128
     assert not img[128:].any() and not img[:, 256:].any() and img[:128, :256].any()
+
+
+def test_sample_sharded_ranks_render_the_same_frame():
+    """tools/pathtrace.py with 2 ranks (gloo rehearsal on one GPU: the ranks share device 0, frames are summed on the CPU;
+    the real run is nccl, one rank per GPU): the summed frame and the ray count equal the single-process run's."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "pathtrace.py")
+    common = ["--spp", "4", "--width", "512", "--height", "384", "--grid", "96"]
+    one = subprocess.run([sys.executable, tool] + common, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env = dict(os.environ, RACC_BENCH_BACKEND="gloo", RACC_BENCH_DEVICE="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", tool] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1]); b = json.loads(two.stdout.strip().splitlines()[-1])
+    assert b["n_gpus"] == 2 and a["frame_md5"] == b["frame_md5"] and a["rays_traced"] == b["rays_traced"]

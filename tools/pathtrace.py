@@ -35,10 +35,17 @@ def main():
     from rayaccel_amd import synth
     from rayaccel_amd.shard import shard_range
     from rayaccel_amd.engine import path_trace
+    # RACC_BENCH_BACKEND=gloo + RACC_BENCH_DEVICE=0 rehearse the N>1 flow on a 1-GPU box (ranks share GPU 0, frames are summed
+    # on the CPU); the real thing is nccl (= RCCL over xGMI), one rank per GPU.
+    backend = os.environ.get("RACC_BENCH_BACKEND", "nccl")
+    local = int(os.environ.get("RACC_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     scene_file = args.scene
     tmp = None
     if scene_file is None:
@@ -55,8 +62,9 @@ def main():
     t0 = time.perf_counter()
     img, st = path_trace(scene_file, args.width, args.height, first, max(1, last - first), device=local, max_depth=args.depth, cpu_threads=args.threads,
                          shading=args.shading, samples_per_batch=args.batch)
-    rays = torch.tensor([float(st["rays_traced"]), st["seconds"]], dtype=torch.float64, device="cuda")
-    frame = torch.from_numpy(img).cuda()
+    dev = "cuda" if backend == "nccl" or world == 1 else "cpu"
+    rays = torch.tensor([float(st["rays_traced"]), st["seconds"]], dtype=torch.float64, device=dev)
+    frame = torch.from_numpy(img).to(dev)
     if world > 1:
         dist.reduce(frame, 0, op=dist.ReduceOp.SUM)                 # RCCL: the one exchange step (W*H*3 doubles per rank)
         tot = rays.clone(); dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -70,6 +78,8 @@ def main():
         os.unlink(tmp.name)
     if rank == 0:
         mean = (frame / args.spp).cpu().numpy()
+        import hashlib
+        digest = hashlib.md5(np.ascontiguousarray(frame.cpu().numpy()).tobytes()).hexdigest()      # of the SUM of radiance: equal for any N
         if args.out:
             with open(args.out, "wb") as f:
                 f.write(b"PF\n%d %d\n-1.0\n" % (args.width, args.height))
@@ -79,7 +89,7 @@ def main():
                           "unit": "Mrays/s", "n_gpus": world, "rays_traced": int(total_rays), "render_seconds": round(render_s, 3),
                           "wall_seconds_incl_scene_build": round(wall, 3), "spp": args.spp, "width": args.width, "height": args.height,
                           "tiles": [st["tiles_x"], st["tiles_y"]], "max_depth": st["max_depth"], "shade_threads_per_rank": st["threads"],
-                          "mean_luminance": float(mean.mean()), "data": "synthetic", "scene": name}), flush=True)
+                          "mean_luminance": float(mean.mean()), "frame_md5": digest, "data": "synthetic", "scene": name}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
