@@ -1,0 +1,38 @@
+"""GPU tests of bench.py itself: the one-line JSON contract at N=1 and the N>1 flow (rehearsed with gloo on one GPU: the
+ranks share device 0; the real run is nccl = RCCL, one rank per GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "config", "roofline", "cpu_baseline"}
+
+
+def _line(cmd, env=None):
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip() and not l.startswith("[Gloo]")]      # gloo's own chatter (rehearsal only)
+    assert len(lines) == 1, "bench must print exactly one line on stdout: %r" % lines[-3:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    d = _line([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--grid", "128", "--no-extras"])
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["unit"] == "Mrays/s"
+    assert d["value"] > 0 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0 and d["roofline"]["achieved"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+
+
+def test_two_ranks_rehearsal():
+    env = dict(os.environ, RACC_BENCH_BACKEND="gloo", RACC_BENCH_DEVICE="0")
+    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29543", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--grid", "128", "--no-extras"], env)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["cpu_baseline"] is None      # the CPU legs run at N=1 only
+    assert d["config"]["parallelism"].startswith("rays sharded x2")
