@@ -25,6 +25,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -58,7 +59,8 @@ struct TraverseArgs {
     const uint32_t* remap;
     const float4* env;        // RGBA32F probe image or nullptr
     uint32_t envW, envH;
-    uint32_t* cursor;         // [0] ray cursor, [1] finished-block counter, [2] watchdog trips
+    uint32_t* cursor;         // [0] ray cursor, [1] finished-block counter
+    uint32_t* trips;          // watchdog trips: one word of host-mapped memory per context, so the host sees it without a copy
     uint32_t* spill;          // [spillLevels][gridThreads]
     uint32_t spillStride;     // gridThreads
     uint32_t chunk;           // rays per cursor dequeue
@@ -275,7 +277,7 @@ __global__ void __launch_bounds__(BLOCK) traverseKernelV2(const TraverseArgs a) 
 
     for (uint32_t iter = 0;; ++iter) {
         if (iter >= a.maxIters) {
-            if (lane == 0) atomicAdd(a.cursor + 2, 1u);
+            if (lane == 0) __hip_atomic_fetch_add(a.trips, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
         unsigned long long cyTop = 0;
@@ -542,6 +544,10 @@ struct racc_hip_ctx {
     int numCUs = 0;
     racc_hip_options opts{};
     Lane lanes[RACC_HIP_MAX_LANES];
+    uint32_t* hostTrips = nullptr;       // host-mapped: kernels bump it when a wave hits the iteration limit
+    uint32_t* devTrips = nullptr;        // the device alias of the same word
+    std::atomic<uint32_t> seenTrips{0};
+    uint32_t maxIters = 1u << 24;        // RACC_MAX_ITERS overrides (tests)
 };
 
 struct racc_hip_scene {
@@ -747,7 +753,8 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     if (a.chunk > 65536u) a.chunk = 65536u;      // grid waves x chunk (the statically assigned first chunks) must stay far below 2^32
     a.refillMin = optOr(ctx->opts.refill_min, 32u);
     a.leafMin = optOr(ctx->opts.leaf_min, 12u);
-    a.maxIters = 1u << 24;
+    a.maxIters = ctx->maxIters;
+    a.trips = ctx->devTrips;
     a.tailActive = ctx->opts.tail_active ? (ctx->opts.tail_active > 64u ? 0u : ctx->opts.tail_active) : 32u;   // >64 disables
     a.regroup = optOr(ctx->opts.regroup_period, 8u);
     a.thinReps = optOr(ctx->opts.thin_reps, 8u);
@@ -791,6 +798,19 @@ int ensureStaging(Lane& lane, uint32_t count) {
     HIP_TRY(hipMalloc(&lane.dRays, size_t(cap) * 32), "hipMalloc(staging rays)");
     HIP_TRY(hipMalloc(&lane.dResults, size_t(cap) * 16), "hipMalloc(staging results)");
     lane.capacity = cap;
+    return RACC_HIP_OK;
+}
+
+// After a synchronisation: did a wave of any launch since the last check give up at the iteration limit?  (Only a scene
+// blob that passed validation and still does not terminate, or an absurd RACC_MAX_ITERS, can do that; its results are
+// incomplete and the caller must hear about it.)
+int checkWatchdog(racc_hip_ctx* ctx) {
+    const uint32_t t = *static_cast<volatile uint32_t*>(ctx->hostTrips);
+    uint32_t seen = ctx->seenTrips.load();
+    while (seen != t) {
+        if (ctx->seenTrips.compare_exchange_weak(seen, t))
+            return fail(RACC_HIP_ERR_DEVICE, "traversal watchdog: a wave exceeded the iteration limit, results of the launch are incomplete (corrupt scene blob?)");
+    }
     return RACC_HIP_OK;
 }
 
@@ -845,6 +865,12 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
         hipError_t e3 = e2 == hipSuccess ? hipMemset(l.cursor, 0, 256) : e2;
         if (e3 != hipSuccess) { racc_hip_destroy(ctx); return fail(RACC_HIP_ERR_DEVICE, "lane setup", e3); }
     }
+    {
+        hipError_t e1 = hipHostMalloc(reinterpret_cast<void**>(&ctx->hostTrips), 64, hipHostMallocMapped);
+        if (e1 == hipSuccess) { *ctx->hostTrips = 0; e1 = hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->devTrips), ctx->hostTrips, 0); }
+        if (e1 != hipSuccess) { racc_hip_destroy(ctx); return fail(RACC_HIP_ERR_DEVICE, "watchdog word", e1); }
+        if (const char* m = std::getenv("RACC_MAX_ITERS")) { const long long v = std::atoll(m); if (v > 0 && v < (1ll << 31)) ctx->maxIters = uint32_t(v); }
+    }
     *out = ctx;
     return RACC_HIP_OK;
 }
@@ -852,6 +878,8 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
 int racc_hip_destroy(racc_hip_ctx* ctx) {
     if (!ctx) return RACC_HIP_OK;
     hipSetDevice(ctx->device);
+    hipDeviceSynchronize();              // launches given a caller's own stream (racc_hip_intersect_device) included
+    if (ctx->hostTrips) hipHostFree(ctx->hostTrips);
     for (Lane& l : ctx->lanes) {
         if (l.stream) hipStreamSynchronize(l.stream);
         for (hipEvent_t ev : l.events) hipEventDestroy(ev);
@@ -1002,7 +1030,7 @@ int racc_hip_wait(racc_hip_ctx* ctx, uint32_t lane) {
     if (int rc = checkLane(ctx, lane)) return rc;
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     HIP_TRY(hipStreamSynchronize(ctx->lanes[lane].stream), "hipStreamSynchronize");
-    return RACC_HIP_OK;
+    return checkWatchdog(ctx);
 }
 
 int racc_hip_intersect(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
@@ -1060,7 +1088,7 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
         if (int rc = launchEnvShade(ctx, l, l.stream, env, l.dResults, uint32_t(total))) return rc;
         HIP_TRY(copyRange(1, 0, total, l.stream), "D2H results");
         HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
-        return RACC_HIP_OK;
+        return checkWatchdog(ctx);
     }
     // Large batches: cut into slices so that the PCIe copy of slice k+1 (in) and of slice k-1 (out) run beside the kernel of
     // slice k (PCIe is full duplex; a 1M-ray batch is 32 MiB in, 16 MiB out, 0.9 ms of copies against 0.4 ms of kernel).
@@ -1086,7 +1114,7 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
     }
     HIP_TRY(hipStreamSynchronize(l.copyOut), "hipStreamSynchronize");
     HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
-    return RACC_HIP_OK;
+    return checkWatchdog(ctx);
 }
 
 int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
@@ -1125,7 +1153,7 @@ int racc_hip_intersect_device_timed(racc_hip_ctx* ctx, const racc_hip_scene* sce
     for (uint32_t i = 0; i < iters; ++i)
         HIP_TRY(hipEventElapsedTime(&ms[i], l.events[2 * i], l.events[2 * i + 1]), "hipEventElapsedTime");
     l.info.last_kernel_ms = ms[iters - 1];
-    return RACC_HIP_OK;
+    return checkWatchdog(ctx);
 }
 
 int racc_hip_get_launch_info(racc_hip_ctx* ctx, uint32_t lane, racc_hip_launch_info* info) {
@@ -1178,7 +1206,7 @@ int racc_hip_synchronize(racc_hip_ctx* ctx) {
     if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
-    return RACC_HIP_OK;
+    return checkWatchdog(ctx);
 }
 
 }  // extern "C"

@@ -287,6 +287,25 @@ def test_pinned_host_block(gpu_ctx, small):
     assert_bit_exact(got, orc.traverse(small["blobs"], rays, env=small["sc"]["env"]), "pinned block")
 
 
+def test_watchdog_trip_is_reported(small, small_host, monkeypatch):
+    """A wave that hits the iteration limit leaves results unwritten: the next synchronising call must say so (the limit is
+    2^24 iterations; RACC_MAX_ITERS lowers it for this test), once, and the context stays usable."""
+    monkeypatch.setenv("RACC_MAX_ITERS", "3")
+    with ra.Context(device=0) as ctx:
+        scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
+        with pytest.raises(ra.RaccError) as e:
+            ctx.intersect(scene, None, small["primary"][:5000])
+        assert e.value.code == -2 and "watchdog" in str(e.value)
+        ctx.synchronize()                                         # reported once
+        scene.destroy()
+    monkeypatch.delenv("RACC_MAX_ITERS")
+    with ra.Context(device=0) as ctx:
+        scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
+        rays = small["primary"][:5000]
+        assert_bit_exact(ctx.intersect(scene, None, rays), orc.traverse(small["blobs"], rays), "after a watchdog trip elsewhere")
+        scene.destroy()
+
+
 def test_sliced_host_path_with_page_locked_streams(gpu_ctx, full):
     """Page-locked host arrays and >= 512k rays take the pipelined path (copies of one slice beside the kernel of another);
     slice boundaries fall inside the ray streams.  Same results as the plain path, stream by stream, bit for bit."""
