@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_MEASURED_GBS = 6290.0      # same guide: float4-copy ceiling
 RAYS_PER_BATCH = 1 << 20
-KERNEL_NAME = "traverseKernelV2"
+KERNEL_NAME = "traverseKernelV8"
 
 
 def _committed_traffic():
@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (profiling runs)")
     ap.add_argument("--grid", type=int, default=700, help="height-field resolution of battlefield-synth (700 = full)")
+    ap.add_argument("--engine-opts", default="", help="JSON dict of racc_hip_options overrides (kernel A/B and profiling runs only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,7 +102,8 @@ def main():
     full = args.grid == 700
     sc = synth.battlefield_synth() if full else synth.battlefield_synth(grid=args.grid, boxes=args.grid * 6, quads=args.grid * 28)
     host = ra.HostScene(sc["vertices"], sc["indices"])
-    ctx = ra.Context(device=device)
+    engine_opts = json.loads(args.engine_opts) if args.engine_opts else {}
+    ctx = ra.Context(device=device, **engine_opts)
     scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
     env = ctx.create_environment(sc["env"])
 

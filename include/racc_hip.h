@@ -54,7 +54,10 @@ typedef struct racc_hip_options {
     uint32_t regroup_period;   /* V3 kernels: scheduling iterations between workgroup-wide regroupings; 0 => default */
     uint32_t thin_reps;        /* V2 kernels: inner steps a thin wave runs per scheduling iteration; 0 => default (8) */
     uint32_t inner_reps;       /* V2 kernels: inner steps any other wave runs per scheduling iteration; 0 => default (3) */
-    uint32_t reserved[5];
+    uint32_t coop_same_pct;    /* V7 kernels: inner steps fetch nodes quad-cooperatively through LDS-DMA while fewer than this
+                                  percentage of the inner lanes hold the same node as their quad neighbour (divergent waves);
+                                  0 => default (50), > 100 => never, 100 => always */
+    uint32_t reserved[4];
 } racc_hip_options;
 
 typedef struct racc_hip_scene_info {
@@ -77,6 +80,9 @@ typedef struct racc_hip_launch_info {
 
 const char* racc_hip_last_error(void);             /* thread-local, never NULL */
 const char* racc_hip_version(void);
+/* 1 if racc_hip_options::kernel_variant = n selects a kernel of this build (0 = the default always does; the earlier
+ * generations and ablations exist only in a `make EXPERIMENTAL=1` build), else 0.  Needs no GPU. */
+int racc_hip_variant_available(uint32_t kernel_variant);
 
 /* ≙ clGetDeviceIDs, RayAccelerator.cpp:467-478 (reference picks devices[0]). */
 int racc_hip_device_count(int* count);

@@ -41,7 +41,7 @@ class RaccError(RuntimeError):
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("lanes", C.c_uint32), ("waves_per_simd", C.c_uint32),
                 ("kernel_variant", C.c_uint32), ("refill_min", C.c_uint32), ("leaf_min", C.c_uint32),
-                ("chunk", C.c_uint32), ("tail_active", C.c_uint32), ("regroup_period", C.c_uint32), ("thin_reps", C.c_uint32), ("inner_reps", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+                ("chunk", C.c_uint32), ("tail_active", C.c_uint32), ("regroup_period", C.c_uint32), ("thin_reps", C.c_uint32), ("inner_reps", C.c_uint32), ("coop_same_pct", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
 
 class SceneInfo(C.Structure):
@@ -61,6 +61,7 @@ _P = C.POINTER
 ABI = {
     "racc_hip_last_error": (C.c_char_p, []),
     "racc_hip_version": (C.c_char_p, []),
+    "racc_hip_variant_available": (_i, [_u32]),
     "racc_hip_device_count": (_i, [_P(_i)]),
     "racc_hip_create": (_i, [_i, _P(Options), _P(_vp)]),
     "racc_hip_destroy": (_i, [_vp]),
@@ -97,7 +98,7 @@ _lib = None
 
 def build_library(force=False):
     """Compile libracc_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("racc_hip.hip", "racc_kernels_experimental.inc", "scene_build.cpp", "racc_api.cpp", "pathtracer.cpp", "pt_device.hip", "pt_shade.h",
+    srcs = [os.path.join(CSRC, f) for f in ("racc_hip.hip", "racc_device.inc", "racc_kernels_experimental.inc", "scene_build.cpp", "racc_api.cpp", "pathtracer.cpp", "pt_device.hip", "pt_shade.h",
                                                  "pt_scene.h", "Makefile")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("racc_hip.h", "RayAccelerator.h")]
     srcs.append(os.path.join(_HERE, "..", "tests", "cpp", "render_check.cpp"))
@@ -106,6 +107,12 @@ def build_library(force=False):
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", CSRC])
     return LIB_PATH
+
+
+def available_variants(upto=64):
+    """kernel_variant numbers this build of the library accepts (the shipped build: the V8 rows only)."""
+    lib = load_library()
+    return [v for v in range(1, upto + 1) if lib.racc_hip_variant_available(v)]
 
 
 def load_library():
@@ -236,13 +243,14 @@ class DeviceBuffer:
 class Context:
     """≙ racc::Context for the GPU intersect path; one per (process, GPU)."""
 
-    def __init__(self, device=0, lanes=0, waves_per_simd=0, refill_min=0, leaf_min=0, chunk=0, kernel_variant=0, tail_active=0, regroup_period=0, thin_reps=0, inner_reps=0):
+    def __init__(self, device=0, lanes=0, waves_per_simd=0, refill_min=0, leaf_min=0, chunk=0, kernel_variant=0, tail_active=0, regroup_period=0, thin_reps=0, inner_reps=0, coop_same_pct=0):
         lib = load_library()
         o = Options()
         o.struct_size = C.sizeof(Options)
         o.lanes, o.waves_per_simd, o.refill_min, o.leaf_min, o.chunk, o.kernel_variant = lanes, waves_per_simd, refill_min, leaf_min, chunk, kernel_variant
         o.tail_active, o.regroup_period, o.thin_reps = tail_active, regroup_period, thin_reps
         o.inner_reps = inner_reps
+        o.coop_same_pct = coop_same_pct
         h = C.c_void_p()
         _check(lib.racc_hip_create(device, C.byref(o), C.byref(h)))
         self._h = h

@@ -103,13 +103,18 @@ def test_invalid_and_unbounded_rays(gpu_ctx, small):
 def test_deep_stack_spills_to_global(gpu_ctx):
     blobs = comb_scene(40)
     scene = gpu_ctx.upload_scene(blobs["nodes"], blobs["pairs"], blobs["remap"])
-    assert scene.info["inner_height"] == 40 and scene.info["spill_levels"] == 24
+    assert scene.info["inner_height"] == 40 and scene.info["spill_levels"] == 28      # default kernel: 12 stack entries in LDS
     o = np.stack([np.linspace(-20, 20, 300), np.linspace(-15, 15, 300), np.full(300, -10.0)], 1)
     rays = make_rays(o, [[0, 0, 1]] * 300)
     ref, _, _, depth = orc.traverse(blobs, rays, counters=True)
     assert depth.max() == 40
     assert_bit_exact(gpu_ctx.intersect(scene, None, rays), ref, "comb")
     scene.destroy()
+    with ra.Context(device=0, kernel_variant=41) as ctx:      # the 8-entry instantiation: 32 levels in the spill
+        scene = ctx.upload_scene(blobs["nodes"], blobs["pairs"], blobs["remap"])
+        assert scene.info["spill_levels"] == 32
+        assert_bit_exact(ctx.intersect(scene, None, rays), ref, "comb, 8-entry LDS stack")
+        scene.destroy()
 
 
 def test_malformed_blobs_are_rejected(gpu_ctx, small_host):
@@ -132,7 +137,7 @@ def test_launch_options_do_not_change_results(small_scene, small_host, small):
     ref = orc.traverse(small["blobs"], rays, env=small_scene["env"])
     for opt in (dict(waves_per_simd=1, refill_min=1, leaf_min=1, chunk=1), dict(waves_per_simd=8, refill_min=64, leaf_min=64, chunk=4096),
                 dict(waves_per_simd=3, refill_min=20, leaf_min=7, chunk=100), dict(lanes=1, chunk=64),
-                *[dict(kernel_variant=v) for v in range(1, 31)], dict(kernel_variant=18, regroup_period=3), dict(tail_active=65),
+                *[dict(kernel_variant=v) for v in ra.engine.available_variants()], *([dict(kernel_variant=18, regroup_period=3)] if 18 in ra.engine.available_variants() else []), dict(tail_active=65), dict(coop_same_pct=100), dict(coop_same_pct=101), dict(kernel_variant=41, coop_same_pct=100, refill_min=5, leaf_min=3, inner_reps=7),
                 dict(chunk=1 << 30), dict(thin_reps=1, inner_reps=1), dict(thin_reps=3, tail_active=40, inner_reps=2), dict(thin_reps=64, tail_active=64), dict(inner_reps=16)):
         with ra.Context(device=0, **opt) as ctx:
             scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
@@ -256,7 +261,7 @@ def test_scheduling_statistics_variant(small_scene, small_host, small):
     visit / pair test of the oracle's count must appear as a live lane in some step."""
     rays = _batches(small)["diffuse"]
     ref, nv, npairs, _ = orc.traverse(small["blobs"], rays, counters=True)
-    for variant in (9, 12, 21):
+    for variant in [v for v in (9, 12, 21, 42) if v in ra.engine.available_variants()]:
         with ra.Context(device=0, kernel_variant=variant) as ctx:
             scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
             ctx.read_stats()
@@ -267,6 +272,10 @@ def test_scheduling_statistics_variant(small_scene, small_host, small):
             # and a thin wave's second body also serves lanes that changed kind in the first one, so they under-count.
             if variant == 9:
                 assert st["inner_lanes"] == int(nv.sum()) and st["leaf_lanes"] == int(npairs.sum())
+            elif variant == 42:     # V8: the inner steps run inside the assembly block and are not counted
+                assert st["leaf_lanes"] == int(npairs.sum()) and st["waves"] > 0
+                scene.destroy()
+                continue
             else:
                 assert 0.9 * int(nv.sum()) <= st["inner_lanes"] <= int(nv.sum()) and st["leaf_lanes"] == int(npairs.sum())
             assert st["inner_iters"] * 64 >= st["inner_lanes"] and st["waves"] > 0
@@ -290,11 +299,11 @@ def test_pinned_host_block(gpu_ctx, small):
 def test_watchdog_trip_is_reported(small, small_host, monkeypatch):
     """A wave that hits the iteration limit leaves results unwritten: the next synchronising call must say so (the limit is
     2^24 iterations; RACC_MAX_ITERS lowers it for this test), once, and the context stays usable."""
-    monkeypatch.setenv("RACC_MAX_ITERS", "3")
+    monkeypatch.setenv("RACC_MAX_ITERS", "2")       # scheduling headers per wave; rays that hit the terrain need dozens
     with ra.Context(device=0) as ctx:
         scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
         with pytest.raises(ra.RaccError) as e:
-            ctx.intersect(scene, None, small["primary"][:5000])
+            ctx.intersect(scene, None, small["primary"])
         assert e.value.code == -2 and "watchdog" in str(e.value)
         ctx.synchronize()                                         # reported once
         scene.destroy()

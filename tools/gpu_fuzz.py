@@ -21,11 +21,11 @@ pool = pool[rng.permutation(len(pool))]
 ref_pool = orc.traverse(blobs, pool, env=sc["env"], threads=8)
 bad = 0
 for rnd in range(rounds):
-    opt = dict(kernel_variant=int(rng.choice([0, 0, 0, 22, 23, 24, 17, 11, 1])), lanes=int(rng.integers(1, 5)))
+    opt = dict(kernel_variant=int(rng.choice([0, 0, 0, 41, 43] + [v for v in (22, 23, 24, 17, 11, 1, 31, 34, 38) if v in ra.engine.available_variants()])), lanes=int(rng.integers(1, 5)))
     if rng.random() < 0.6:
         opt.update(waves_per_simd=int(rng.integers(1, 9)), refill_min=int(rng.integers(1, 65)), leaf_min=int(rng.integers(1, 65)),
                    chunk=int(rng.choice([1, 7, 32, 64, 100, 128, 1000])), tail_active=int(rng.integers(1, 70)),
-                   thin_reps=int(rng.integers(1, 20)), inner_reps=int(rng.integers(1, 9)))
+                   thin_reps=int(rng.integers(1, 20)), inner_reps=int(rng.integers(1, 9)), coop_same_pct=int(rng.choice([0, 1, 25, 100, 101])))
     with ra.Context(device=0, **opt) as ctx:
         scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
         env = ctx.create_environment(sc["env"])
