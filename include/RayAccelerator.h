@@ -36,9 +36,16 @@ struct Environment;
 struct GpuContextTag;
 typedef GpuContextTag* GpuContext;                       // replaces cl_context (reference :33)
 
+#define RACC_MAX_DEVICES 8                                // GPUs of one node
+
 // Handle for GPU `ordinal` of this process (0-based; with one process per GPU pass LOCAL_RANK).
 // Returns null if no gfx950 device with that ordinal exists.
 GpuContext gpuContextForDevice(int ordinal);
+// Handle for several GPUs driven by ONE context (the reference's cl_context picks devices[0], RayAccelerator.cpp:467-478):
+// the scene and environment are replicated on each, ray streams are sharded over them as whole streams, results land in
+// place — no exchange between GPUs on this path.  `ordinals` may repeat an entry (two engine contexts on one GPU: rehearsal).
+GpuContext gpuContextForDevices(const int* ordinals, unsigned count);
+GpuContext gpuContextForAllDevices();
 
 struct Configuration {                                   // reference :32-42
     GpuContext gpuContext;
@@ -118,6 +125,9 @@ void destroy(Environment* environment);                  // reference :113
 // One frame: spawn until exhausted, intersect on the GPU, shade, repeat until no rays are in flight.
 // Called from one application thread; blocks (reference RayAccelerator.cpp:738-759).
 Stats render(Context* context, Scene* scene, Environment* environment, RenderCallbacks callbacks);
+// Extension: null after a clean render(); otherwise why the last frame ended early (a device error; the reference ignores
+// those, RayAccelerator.cpp:393-403).  The frame's remaining streams were dropped; the context stays usable.
+const char* lastError(Context* context);
 
 }  // namespace racc
 

@@ -34,6 +34,7 @@ extern "C" {
 #define RACC_HIP_ERR_NOMEM         -5
 
 #define RACC_HIP_MAX_LANES          8   /* >= gpuSubmissionThreads (RayAccelerator.cpp:436) */
+#define RACC_HIP_LANE_AUTO 0xFFFFFFFFu  /* racc_hip_intersect_device: the engine picks the lane, round robin; racc_hip_wait: all lanes */
 
 typedef struct racc_hip_ctx   racc_hip_ctx;    /* one per (process, GPU) */
 typedef struct racc_hip_scene racc_hip_scene;  /* device-resident flattened BVH2 + pairs */
@@ -57,7 +58,9 @@ typedef struct racc_hip_options {
     uint32_t coop_same_pct;    /* V7 kernels: inner steps fetch nodes quad-cooperatively through LDS-DMA while fewer than this
                                   percentage of the inner lanes hold the same node as their quad neighbour (divergent waves);
                                   0 => default (50), > 100 => never, 100 => always */
-    uint32_t reserved[4];
+    uint32_t time_kernels;     /* != 0: an event pair around every traversal kernel (racc_hip_read_kernel_times); costs two
+                                  hipEventRecord per launch, so off by default */
+    uint32_t reserved[3];
 } racc_hip_options;
 
 typedef struct racc_hip_scene_info {
@@ -138,7 +141,13 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
                                const uint32_t* counts, uint32_t lane);
 
 /* Device-resident variant: d_rays/d_results are device pointers (e.g. torch tensors' data_ptr()).
- * `stream` is a hipStream_t passed as void* (NULL => the lane's own stream).  Asynchronous. */
+ * `stream` is a hipStream_t passed as void* (NULL => the lane's own stream).  Asynchronous.
+ * A lane owns one ray cursor and spill area, so its launches never overlap: a launch that goes to another stream than the
+ * lane's previous one first waits (on the device) for that one.  Launches on DIFFERENT lanes do overlap — one's drain hides
+ * under the next one's bulk — which is how the reference keeps its gpuSubmissionThreads queues busy
+ * (RayAccelerator.cpp:711-717).  lane = RACC_HIP_LANE_AUTO rotates over the lanes, so a single-threaded caller that issues
+ * batch after batch (stream = NULL) gets that overlap without managing lanes; racc_hip_wait(ctx, RACC_HIP_LANE_AUTO) or
+ * racc_hip_synchronize then waits for all of them. */
 int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
                               const void* d_rays, void* d_results, uint32_t count,
                               uint32_t lane, void* stream);
@@ -148,6 +157,9 @@ int racc_hip_intersect_device_timed(racc_hip_ctx* ctx, const racc_hip_scene* sce
                                     const void* d_rays, void* d_results, uint32_t count,
                                     uint32_t lane, uint32_t iters, float* ms);
 int racc_hip_get_launch_info(racc_hip_ctx* ctx, uint32_t lane, racc_hip_launch_info* info);
+/* With racc_hip_options::time_kernels: durations (ms, HIP events on the stream each launch went to) of the lane's traversal
+ * kernels since the last call, oldest first, at most `capacity` (the engine keeps the last 256); *n = how many.  Waits for them. */
+int racc_hip_read_kernel_times(racc_hip_ctx* ctx, uint32_t lane, float* ms, uint32_t capacity, uint32_t* n);
 /* Scheduling statistics accumulated by the debug kernel variant (kernel_variant 9) on a lane:
  * [0] inner-step iterations [1] lanes active in them [2] leaf-step iterations [3] lanes active in them
  * [4] refill iterations [5] rays loaded [6] cursor dequeues [7] waves; shader-clock cycles summed over waves:
@@ -161,6 +173,28 @@ int racc_hip_free(racc_hip_ctx* ctx, void* d_ptr);
 int racc_hip_memcpy_h2d(racc_hip_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 int racc_hip_memcpy_d2h(racc_hip_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
 int racc_hip_synchronize(racc_hip_ctx* ctx);
+/* HIP streams for hosts that do not bring their own (passed back as the `stream` of racc_hip_intersect_device). */
+int racc_hip_stream_create(racc_hip_ctx* ctx, void** stream);
+int racc_hip_stream_synchronize(racc_hip_ctx* ctx, void* stream);      /* also reports a watchdog trip */
+int racc_hip_stream_destroy(racc_hip_ctx* ctx, void* stream);
+
+/* ---- multi-GPU: hit-record exchange over RCCL/xGMI ------------------------------------------------
+ * The path shards without any exchange: rays never interact, the scene is read-only (Scene.cpp:342-346), so every GPU
+ * traces its contiguous shard of a batch (one process per GPU, or one racc::Context over several GPUs).  Only a GPU-side
+ * consumer that needs EVERY hit on EVERY GPU needs the step below: one ncclAllGather of the 16-byte Result records, a
+ * single message per rank.  librccl is bound at run time (dlopen); these entries fail with RACC_HIP_ERR_DEVICE if it is
+ * absent.  No counterpart in the reference (it drives one device, RayAccelerator.cpp:467-478).
+ *   rank 0: racc_hip_comm_unique_id(&id); the host program ships the 128 bytes to the other ranks (MPI, torch.distributed,
+ *   a file); every rank: racc_hip_comm_init_rank(ctx, &id, rank, nranks, &comm);
+ *   per batch: racc_hip_allgather_results(comm, d_shard, d_all, rays_per_rank, stream)  — every rank contributes
+ *   rays_per_rank records (pad the last shard); d_all holds nranks * rays_per_rank records, rank r's at r * rays_per_rank;
+ *   in place if d_shard == d_all + rank * rays_per_rank.  Asynchronous on `stream` (hipStream_t as void*, NULL = default). */
+typedef struct racc_hip_comm racc_hip_comm;
+typedef struct racc_hip_comm_id { char bytes[128]; } racc_hip_comm_id;      /* = ncclUniqueId */
+int racc_hip_comm_unique_id(racc_hip_comm_id* id);
+int racc_hip_comm_init_rank(racc_hip_ctx* ctx, const racc_hip_comm_id* id, int rank, int nranks, racc_hip_comm** out);
+int racc_hip_allgather_results(racc_hip_comm* comm, const void* d_send, void* d_recv, uint32_t count_per_rank, void* stream);
+int racc_hip_comm_destroy(racc_hip_comm* comm);
 
 /* ---- host-side scene build (no GPU needed) ---------------------------------------------------
  * ≙ the GPU branch of racc::createScene, Scene.cpp:216-339: createBvh2 (Bvh2.cpp:772-907) →

@@ -35,19 +35,29 @@
 
 namespace racc {
 
+// What a GpuContext handle points at: the GPUs of this process a context drives (replaces the reference's cl_context,
+// which picks devices[0] of one platform, RayAccelerator.cpp:467-478).  Entries may repeat an ordinal (rehearsal of the
+// multi-GPU flow on a one-GPU box).
+struct GpuContextTag {
+    uint32_t count;
+    int ordinals[RACC_MAX_DEVICES];
+};
+
 struct Scene {
     Context* context;
-    racc_hip_scene* device;
+    std::vector<racc_hip_scene*> devices;     // one replica per GPU of the context (the scene is read-only: Scene.cpp:342-346)
 };
 
 struct Environment {
     Context* context;
-    racc_hip_env* device;
+    std::vector<racc_hip_env*> devices;
 };
 
 struct Context {
     Configuration configuration;
-    racc_hip_ctx* hip = nullptr;
+    std::vector<racc_hip_ctx*> hips;          // one engine context per GPU
+    bool failed = false;                      // a device error ended the current frame early (lastError)
+    char error[512] = {0};
 
     std::vector<RayStream> streams;
     char* block = nullptr;           // all rays/results, 4096-aligned per array (reference :523-531,616-631)
@@ -197,7 +207,11 @@ void cpuWorker(Context* c, unsigned thread) {   // reference cpuWorkerThread (GP
     }
 }
 
-void gpuWorker(Context* c, unsigned lane) {   // reference gpuWorkerThread, :335-414
+void gpuWorker(Context* c, unsigned worker) {   // reference gpuWorkerThread, :335-414
+    // submission thread i drives GPU i % nGPUs through that engine context's lane i / nGPUs: ray streams are sharded over the
+    // GPUs as whole streams (rays never interact), results land in place in the page-locked block
+    const unsigned nDev = unsigned(c->hips.size());
+    const unsigned dev = worker % nDev, lane = worker / nDev;
     std::vector<uint32_t> ids;
     std::vector<const void*> rays;
     std::vector<void*> results;
@@ -207,7 +221,12 @@ void gpuWorker(Context* c, unsigned lane) {   // reference gpuWorkerThread, :335
         if (finished(c)) break;
         ids.clear();
         if (!c->readyForTest.empty()) {
-            ids.swap(c->readyForTest);
+            if (nDev == 1) ids.swap(c->readyForTest);
+            else {          // leave the other GPUs their share of what is ready
+                const size_t take = (c->readyForTest.size() + nDev - 1) / nDev;
+                ids.assign(c->readyForTest.end() - take, c->readyForTest.end());
+                c->readyForTest.resize(c->readyForTest.size() - take);
+            }
         } else if (!c->waitingToBeFilled.empty() && c->cpuBusy == 0 && c->readyForShade.empty() && spawnBlocked(c)) {
             ids.swap(c->waitingToBeFilled);             // nothing on the CPU side can add rays any more: flush
         } else {
@@ -228,26 +247,57 @@ void gpuWorker(Context* c, unsigned lane) {   // reference gpuWorkerThread, :335
         Environment* env = c->currentEnvironment;
         lock.unlock();
         const uint64_t t0 = c->profile ? nowNs() : 0;
-        const int rc = racc_hip_intersect_streams(c->hip, scene->device, env ? env->device : nullptr, uint32_t(ids.size()),
+        const int rc = racc_hip_intersect_streams(c->hips[dev], scene->devices[dev], env ? env->devices[dev] : nullptr, uint32_t(ids.size()),
                                                   rays.data(), results.data(), counts.data(), lane);
         if (c->profile) { c->nsGpu += nowNs() - t0; ++c->gpuLaunches; c->gpuStreams += ids.size(); c->gpuRays += total; }
-        if (rc != RACC_HIP_OK) {                         // the reference ignores device errors here (:393-403); we do not
-            complainHip("GPU intersection failed");
-            std::abort();
-        }
         lock.lock();
         --c->gpuBusy;
-        for (uint32_t id : ids) c->readyForShade.push_back(id);
+        if (rc != RACC_HIP_OK) {
+            // The reference ignores device errors here (:393-403).  We end the frame: these streams' results are not valid, so
+            // they are dropped (never shaded), no new rays are spawned, what is already traced drains normally, and render()
+            // returns with lastError(context) set.  The process, the context and the other GPUs stay usable.
+            if (!c->failed) {
+                c->failed = true;
+                std::snprintf(c->error, sizeof(c->error), "GPU intersection failed on device entry %u (%s)", dev, racc_hip_last_error());
+                std::fprintf(stderr, "RayAccelerator: %s\n", c->error);
+            }
+            c->moreRaysExist = false;
+            for (uint32_t id : ids) {
+                c->raysInFlight -= std::min(c->raysInFlight, c->streams[id].count);
+                c->streams[id].count = 0;
+                c->empty.push_back(id);
+            }
+        } else {
+            for (uint32_t id : ids) c->readyForShade.push_back(id);
+        }
         c->wake.notify_all();
     }
 }
 
 }  // namespace
 
-GpuContext gpuContextForDevice(int ordinal) {
+GpuContext gpuContextForDevices(const int* ordinals, unsigned count) {
     int n = 0;
-    if (ordinal < 0 || racc_hip_device_count(&n) != RACC_HIP_OK || ordinal >= n) return nullptr;
-    return reinterpret_cast<GpuContext>(static_cast<uintptr_t>(ordinal) + 1);
+    if (!ordinals || !count || count > RACC_MAX_DEVICES || racc_hip_device_count(&n) != RACC_HIP_OK) return nullptr;
+    GpuContextTag* tag = new (std::nothrow) GpuContextTag();     // lives until the process ends (a handle, like a cl_context the app keeps)
+    if (!tag) return nullptr;
+    tag->count = count;
+    for (unsigned i = 0; i < count; ++i) {
+        if (ordinals[i] < 0 || ordinals[i] >= n) { delete tag; return nullptr; }
+        tag->ordinals[i] = ordinals[i];
+    }
+    return tag;
+}
+
+GpuContext gpuContextForDevice(int ordinal) { return gpuContextForDevices(&ordinal, 1); }
+
+GpuContext gpuContextForAllDevices() {
+    int n = 0;
+    if (racc_hip_device_count(&n) != RACC_HIP_OK || n <= 0) return nullptr;
+    int ordinals[RACC_MAX_DEVICES];
+    const unsigned count = unsigned(std::min(n, int(RACC_MAX_DEVICES)));
+    for (unsigned i = 0; i < count; ++i) ordinals[i] = int(i);
+    return gpuContextForDevices(ordinals, count);
 }
 
 void init() { setFlushToZero(); }   // reference :417-423 (rtcInit has no counterpart)
@@ -260,7 +310,7 @@ Configuration defaultConfiguration(GpuContext gpuContext) {   // reference :429-
     cfg.allowCpuTracing = false;
     const unsigned hw = usableCpus();
     cfg.cpuThreads = std::min(hw > 2 ? hw - 2 : 1u, 32u);   // callbacks only; leave room for the submission threads
-    cfg.gpuSubmissionThreads = 2;                           // one launch + one copy in flight
+    cfg.gpuSubmissionThreads = 2 * (gpuContext ? gpuContext->count : 1u);   // per GPU: one launch + one copy in flight
     cfg.maxRaysInFlight = 4u << 20;                         // reference 262,144 = 29 x its iGPU's 8,960 lanes; MI355X holds 327,680+
     cfg.maxRaysPerSpawn = 128 * 128;
     cfg.cpuTestBatch = 1024;
@@ -278,7 +328,9 @@ Context* createContext(Configuration cfg) {
         complain("invalid configuration (zero threads or batch sizes).");
         return nullptr;
     }
-    if (cfg.gpuSubmissionThreads > RACC_HIP_MAX_LANES) cfg.gpuSubmissionThreads = RACC_HIP_MAX_LANES;
+    const unsigned nDev = cfg.gpuContext->count;
+    if (cfg.gpuSubmissionThreads < nDev) cfg.gpuSubmissionThreads = nDev;                  // every GPU gets a submission thread
+    if (cfg.gpuSubmissionThreads > RACC_HIP_MAX_LANES * nDev) cfg.gpuSubmissionThreads = RACC_HIP_MAX_LANES * nDev;
     Context* c = new (std::nothrow) Context();
     if (!c) { complain("Unable to allocate memory."); return nullptr; }
     c->configuration = cfg;
@@ -286,12 +338,16 @@ Context* createContext(Configuration cfg) {
 
     racc_hip_options opts{};
     opts.struct_size = sizeof(opts);
-    opts.lanes = cfg.gpuSubmissionThreads;
-    const int device = int(reinterpret_cast<uintptr_t>(cfg.gpuContext)) - 1;
-    if (racc_hip_create(device, &opts, &c->hip) != RACC_HIP_OK) {
-        complainHip("Cannot create the GPU context");
-        delete c;
-        return nullptr;
+    opts.lanes = (cfg.gpuSubmissionThreads + nDev - 1) / nDev;
+    for (unsigned d = 0; d < nDev; ++d) {
+        racc_hip_ctx* hip = nullptr;
+        if (racc_hip_create(cfg.gpuContext->ordinals[d], &opts, &hip) != RACC_HIP_OK) {
+            complainHip("Cannot create the GPU context");
+            for (racc_hip_ctx* h : c->hips) racc_hip_destroy(h);
+            delete c;
+            return nullptr;
+        }
+        c->hips.push_back(hip);
     }
 
     // Stream count and size: reference :517-521.
@@ -303,13 +359,13 @@ Context* createContext(Configuration cfg) {
     c->blockBytes = perStream * streamCount;
     if (posix_memalign(reinterpret_cast<void**>(&c->block), 4096, c->blockBytes) != 0) {
         complain("Unable to allocate memory.");
-        racc_hip_destroy(c->hip);
+        for (racc_hip_ctx* h : c->hips) racc_hip_destroy(h);
         delete c;
         return nullptr;
     }
     std::memset(c->block, 0, c->blockBytes);   // ≙ the clear kernel, reference :647-698
-    // Page-lock the whole block once (one hipHostRegister over all streams).
-    c->blockPinned = racc_hip_register_host(c->hip, c->block, c->blockBytes) == RACC_HIP_OK;
+    // Page-lock the whole block once (one portable hipHostRegister over all streams: every GPU can DMA from/to it).
+    c->blockPinned = racc_hip_register_host(c->hips[0], c->block, c->blockBytes) == RACC_HIP_OK;
     if (!c->blockPinned) complainHip("warning: ray streams are not page-locked; PCIe copies will be staged");
 
     c->streams.resize(streamCount);
@@ -348,8 +404,8 @@ void destroy(Context* c) {   // reference :761-788
                      (unsigned long long)c->gpuLaunches.load(), c->gpuLaunches ? double(c->gpuStreams.load()) / double(c->gpuLaunches.load()) : 0.0,
                      c->gpuLaunches ? double(c->gpuRays.load()) / double(c->gpuLaunches.load()) : 0.0);
     }
-    if (c->blockPinned) racc_hip_unregister_host(c->hip, c->block);
-    racc_hip_destroy(c->hip);
+    if (c->blockPinned) racc_hip_unregister_host(c->hips[0], c->block);
+    for (racc_hip_ctx* h : c->hips) racc_hip_destroy(h);
     std::free(c->block);
     delete c;
 }
@@ -374,42 +430,60 @@ Scene* createScene(Context* c, const Vertex* vertices, unsigned vertexCount, con
     const uint32_t* remap = nullptr;
     uint32_t nNodes = 0, nPairsPadded = 0, nPairs = 0, nRemap = 0;
     racc_host_scene_blobs(host, &nodes, &nNodes, &pairs, &nPairsPadded, &nPairs, &remap, &nRemap);
-    racc_hip_scene* dev = nullptr;
-    const int rc = racc_hip_scene_upload(c->hip, nodes, nNodes, pairs, nPairsPadded, remap, nRemap, &dev);
+    Scene* s = new (std::nothrow) Scene{c, {}};
+    if (!s) { racc_host_scene_free(host); complain("Unable to allocate memory."); return nullptr; }
+    for (racc_hip_ctx* hip : c->hips) {          // one replica per GPU
+        racc_hip_scene* dev = nullptr;
+        if (racc_hip_scene_upload(hip, nodes, nNodes, pairs, nPairsPadded, remap, nRemap, &dev) != RACC_HIP_OK) {
+            complainHip("Cannot upload the scene");
+            racc_host_scene_free(host);
+            destroy(s);
+            return nullptr;
+        }
+        s->devices.push_back(dev);
+    }
     racc_host_scene_free(host);
-    if (rc != RACC_HIP_OK) { complainHip("Cannot upload the scene"); return nullptr; }
-    Scene* s = new (std::nothrow) Scene{c, dev};
-    if (!s) { racc_hip_scene_free(c->hip, dev); complain("Unable to allocate memory."); }
     return s;
 }
 
 void destroy(Scene* s) {   // reference Scene.cpp:359-372
     if (!s) return;
-    racc_hip_scene_free(s->context->hip, s->device);
+    for (size_t d = 0; d < s->devices.size(); ++d) racc_hip_scene_free(s->context->hips[d], s->devices[d]);
     delete s;
 }
 
 Environment* createEnvironment(Context* c, const Color* colors, unsigned width, unsigned height) {
     if (!c || !colors) { complain("createEnvironment: null argument."); return nullptr; }
-    racc_hip_env* dev = nullptr;
-    if (racc_hip_env_upload(c->hip, &colors->r, width, height, &dev) != RACC_HIP_OK) {
-        complainHip("Cannot upload the environment");
-        return nullptr;
+    Environment* e = new (std::nothrow) Environment{c, {}};
+    if (!e) { complain("Unable to allocate memory."); return nullptr; }
+    for (racc_hip_ctx* hip : c->hips) {
+        racc_hip_env* dev = nullptr;
+        if (racc_hip_env_upload(hip, &colors->r, width, height, &dev) != RACC_HIP_OK) {
+            complainHip("Cannot upload the environment");
+            destroy(e);
+            return nullptr;
+        }
+        e->devices.push_back(dev);
     }
-    Environment* e = new (std::nothrow) Environment{c, dev};
-    if (!e) { racc_hip_env_free(c->hip, dev); complain("Unable to allocate memory."); }
     return e;
 }
 
 void destroy(Environment* e) {   // reference Environment.cpp:62-67
     if (!e) return;
-    racc_hip_env_free(e->context->hip, e->device);
+    for (size_t d = 0; d < e->devices.size(); ++d) racc_hip_env_free(e->context->hips[d], e->devices[d]);
     delete e;
 }
 
+const char* lastError(Context* c) { return c && c->failed ? c->error : nullptr; }
+
 Stats render(Context* c, Scene* scene, Environment* environment, RenderCallbacks callbacks) {   // reference :738-759
+    if (!c || !scene || !callbacks.spawn || !callbacks.shade) {      // (the reference would hang or crash on these)
+        complain("render: null context, scene or callback.");
+        return Stats{};
+    }
     const uint64_t t0 = c->profile ? nowNs() : 0;
     std::unique_lock<std::mutex> lock(c->mutex);
+    c->failed = false;
     c->currentScene = scene;
     c->currentEnvironment = environment;
     c->currentCallbacks = callbacks;

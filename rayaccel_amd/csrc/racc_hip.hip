@@ -25,7 +25,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <atomic>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -514,8 +517,18 @@ struct Lane {
     hipStream_t copyIn = nullptr, copyOut = nullptr;   // host-buffer path: copies of slice k+1 / k-1 run beside the kernel of slice k
     std::vector<hipEvent_t> pipeEvents;
     racc_hip_launch_info info{};
-    bool pendingEnv = false;             // last traversal launch parked miss directions (V2): envShade must follow
+    bool pendingEnv = false;             // last traversal launch parked miss directions: envShade must follow
+    // A lane owns ONE ray cursor / ticket / spill area, so its launches must not overlap: every launch is followed by
+    // `done` on the stream it went to, and a launch that goes to a different stream than the previous one waits for it.
+    std::mutex mutex;                    // host-side: one thread at a time enqueues on a lane
+    hipEvent_t done = nullptr;
+    hipStream_t lastStream = nullptr;
+    bool everLaunched = false;
+    // opts.time_kernels: an event pair around every traversal kernel, read back by racc_hip_read_kernel_times
+    std::vector<hipEvent_t> ring;        // 2 * kTimeRing events
+    uint32_t ringHead = 0, ringCount = 0;
 };
+constexpr uint32_t kTimeRing = 256;
 
 }  // namespace
 
@@ -527,6 +540,7 @@ struct racc_hip_ctx {
     uint32_t* hostTrips = nullptr;       // host-mapped: kernels bump it when a wave hits the iteration limit
     uint32_t* devTrips = nullptr;        // the device alias of the same word
     std::atomic<uint32_t> seenTrips{0};
+    std::atomic<uint32_t> nextLane{0};   // RACC_HIP_LANE_AUTO: round robin
     uint32_t maxIters = 1u << 24;        // RACC_MAX_ITERS overrides (tests)
 };
 
@@ -765,11 +779,21 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.regroup = optOr(ctx->opts.regroup_period, 8u);
     a.thinReps = optOr(ctx->opts.thin_reps, 8u);
     a.innerReps = optOr(ctx->opts.inner_reps, 3u);
-    a.coopNum = ctx->opts.coop_same_pct ? (ctx->opts.coop_same_pct > 100u ? 0u : ctx->opts.coop_same_pct) : 50u;   // > 100 disables the cooperative fetch
+    a.coopNum = ctx->opts.coop_same_pct ? (ctx->opts.coop_same_pct > 100u ? 0u : ctx->opts.coop_same_pct) : 20u;   // > 100 disables the cooperative fetch
     a.coopDen = 100u;
     a.stats = reinterpret_cast<unsigned long long*>(lane.cursor + 8);
+    // the lane's cursor / ticket / spill serve one launch at a time: a launch on another stream than the lane's previous
+    // one first waits for that one (same stream: stream order already does it)
+    if (lane.everLaunched && lane.lastStream != stream) HIP_TRY(hipStreamWaitEvent(stream, lane.done, 0), "hipStreamWaitEvent(lane)");
+    const bool timed = ctx->opts.time_kernels != 0u && !lane.ring.empty();
+    if (timed) HIP_TRY(hipEventRecord(lane.ring[2 * lane.ringHead], stream), "hipEventRecord");
     hipLaunchKernelGGL(v.kernel, dim3(blocks), dim3(v.block), 0, stream, a);
     HIP_TRY(hipGetLastError(), "launch traverseKernel");
+    if (timed) {
+        HIP_TRY(hipEventRecord(lane.ring[2 * lane.ringHead + 1], stream), "hipEventRecord");
+        lane.ringHead = (lane.ringHead + 1u) % kTimeRing;
+        if (lane.ringCount < kTimeRing) ++lane.ringCount;
+    }
     lane.pendingEnv = v.deferEnv && env != nullptr;
     lane.info.grid_blocks = blocks;
     lane.info.block_threads = uint32_t(v.block);
@@ -778,7 +802,22 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     return RACC_HIP_OK;
 }
 
+// Marks the end of a lane's launch on `stream` (after its last kernel): the next launch of this lane on another stream waits here.
+int markLaneDone(Lane& lane, hipStream_t stream) {
+    HIP_TRY(hipEventRecord(lane.done, stream), "hipEventRecord(lane done)");
+    lane.lastStream = stream;
+    lane.everLaunched = true;
+    return RACC_HIP_OK;
+}
+
+int launchEnvShadeOnly(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc_hip_env* env, void* dResults, uint32_t count);
+
 int launchEnvShade(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc_hip_env* env, void* dResults, uint32_t count) {
+    if (int rc = launchEnvShadeOnly(ctx, lane, stream, env, dResults, count)) return rc;
+    return count ? markLaneDone(lane, stream) : RACC_HIP_OK;
+}
+
+int launchEnvShadeOnly(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc_hip_env* env, void* dResults, uint32_t count) {
     if (!lane.pendingEnv || !env || !count) return RACC_HIP_OK;
     lane.pendingEnv = false;
     uint32_t blocks = (count + 255u) / 256u;
@@ -884,6 +923,11 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
         hipError_t e1 = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
         hipError_t e2 = e1 == hipSuccess ? hipMalloc(reinterpret_cast<void**>(&l.cursor), 256) : e1;
         hipError_t e3 = e2 == hipSuccess ? hipMemset(l.cursor, 0, 256) : e2;
+        if (e3 == hipSuccess) e3 = hipEventCreateWithFlags(&l.done, hipEventDisableTiming);
+        if (e3 == hipSuccess && ctx->opts.time_kernels) {
+            l.ring.resize(2 * kTimeRing, nullptr);
+            for (hipEvent_t& ev : l.ring) if (e3 == hipSuccess) e3 = hipEventCreate(&ev);
+        }
         if (e3 != hipSuccess) { racc_hip_destroy(ctx); return fail(RACC_HIP_ERR_DEVICE, "lane setup", e3); }
     }
     {
@@ -905,6 +949,8 @@ int racc_hip_destroy(racc_hip_ctx* ctx) {
         if (l.stream) hipStreamSynchronize(l.stream);
         for (hipEvent_t ev : l.events) hipEventDestroy(ev);
         for (hipEvent_t ev : l.pipeEvents) hipEventDestroy(ev);
+        for (hipEvent_t ev : l.ring) if (ev) hipEventDestroy(ev);
+        if (l.done) hipEventDestroy(l.done);
         if (l.copyIn) hipStreamDestroy(l.copyIn);
         if (l.copyOut) hipStreamDestroy(l.copyOut);
         if (l.cursor) hipFree(l.cursor);
@@ -1002,7 +1048,7 @@ int racc_hip_env_free(racc_hip_ctx* ctx, racc_hip_env* env) {
 int racc_hip_register_host(racc_hip_ctx* ctx, void* ptr, uint64_t bytes) {
     if (!ctx || !ptr || !bytes) return fail(RACC_HIP_ERR_INVALID, "register_host: bad argument");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
-    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault), "hipHostRegister");
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterPortable), "hipHostRegister");
     return RACC_HIP_OK;
 }
 
@@ -1016,8 +1062,8 @@ int racc_hip_unregister_host(racc_hip_ctx* ctx, void* ptr) {
 int racc_hip_register_stream(racc_hip_ctx* ctx, void* rays, void* results, uint32_t capacity) {
     if (!ctx || !rays || !results || !capacity) return fail(RACC_HIP_ERR_INVALID, "register_stream: bad argument");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
-    HIP_TRY(hipHostRegister(rays, size_t(capacity) * 32, hipHostRegisterDefault), "hipHostRegister(rays)");
-    hipError_t e = hipHostRegister(results, size_t(capacity) * 16, hipHostRegisterDefault);
+    HIP_TRY(hipHostRegister(rays, size_t(capacity) * 32, hipHostRegisterPortable), "hipHostRegister(rays)");
+    hipError_t e = hipHostRegister(results, size_t(capacity) * 16, hipHostRegisterPortable);
     if (e != hipSuccess) { hipHostUnregister(rays); return fail(RACC_HIP_ERR_DEVICE, "hipHostRegister(results)", e); }
     return RACC_HIP_OK;
 }
@@ -1038,6 +1084,7 @@ int racc_hip_intersect_async(racc_hip_ctx* ctx, const racc_hip_scene* scene, con
     if (!rays || !results) return fail(RACC_HIP_ERR_INVALID, "rays/results is NULL");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     Lane& l = ctx->lanes[lane];
+    std::lock_guard<std::mutex> guard(l.mutex);
     HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");     // staging buffers are reused per lane
     if (int rc = ensureStaging(l, count)) return rc;
     HIP_TRY(hipMemcpyAsync(l.dRays, rays, size_t(count) * 32, hipMemcpyHostToDevice, l.stream), "H2D rays");
@@ -1048,9 +1095,24 @@ int racc_hip_intersect_async(racc_hip_ctx* ctx, const racc_hip_scene* scene, con
 }
 
 int racc_hip_wait(racc_hip_ctx* ctx, uint32_t lane) {
-    if (int rc = checkLane(ctx, lane)) return rc;
+    if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
-    HIP_TRY(hipStreamSynchronize(ctx->lanes[lane].stream), "hipStreamSynchronize");
+    if (lane == RACC_HIP_LANE_AUTO) {         // every lane: its own stream and, through `done`, whatever stream its last launch went to
+        for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
+            Lane& l = ctx->lanes[i];
+            std::lock_guard<std::mutex> guard(l.mutex);
+            HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
+            if (l.everLaunched) HIP_TRY(hipEventSynchronize(l.done), "hipEventSynchronize");
+        }
+        return checkWatchdog(ctx);
+    }
+    if (int rc = checkLane(ctx, lane)) return rc;
+    {
+        Lane& l = ctx->lanes[lane];
+        std::lock_guard<std::mutex> guard(l.mutex);
+        HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
+        if (l.everLaunched) HIP_TRY(hipEventSynchronize(l.done), "hipEventSynchronize");
+    }
     return checkWatchdog(ctx);
 }
 
@@ -1077,6 +1139,7 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
     if (!total) return RACC_HIP_OK;
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     Lane& l = ctx->lanes[lane];
+    std::lock_guard<std::mutex> guard(l.mutex);
     HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
     if (int rc = ensureStaging(l, uint32_t(total))) return rc;
     // Copies `what` (0 = rays H2D, 1 = results D2H) of the global ray range [g0, g1) on stream st, stream by stream.
@@ -1140,12 +1203,15 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
 
 int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
                               const void* d_rays, void* d_results, uint32_t count, uint32_t lane, void* stream) {
+    if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
+    if (lane == RACC_HIP_LANE_AUTO) lane = ctx->nextLane.fetch_add(1u) % ctx->opts.lanes;      // round robin: consecutive launches overlap
     if (int rc = checkLane(ctx, lane)) return rc;
     if (!scene) return fail(RACC_HIP_ERR_INVALID, "scene is NULL");
     if (!count) return RACC_HIP_OK;
     if (!d_rays || !d_results) return fail(RACC_HIP_ERR_INVALID, "d_rays/d_results is NULL");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     Lane& l = ctx->lanes[lane];
+    std::lock_guard<std::mutex> guard(l.mutex);
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : l.stream;
     if (int rc = launchTraverse(ctx, l, st, scene, env, d_rays, d_results, count)) return rc;
     return launchEnvShade(ctx, l, st, env, d_results, count);
@@ -1159,6 +1225,7 @@ int racc_hip_intersect_device_timed(racc_hip_ctx* ctx, const racc_hip_scene* sce
     if (!d_rays || !d_results || !count) return fail(RACC_HIP_ERR_INVALID, "timed: empty batch");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     Lane& l = ctx->lanes[lane];
+    std::lock_guard<std::mutex> guard(l.mutex);
     while (l.events.size() < size_t(iters) * 2) {
         hipEvent_t ev;
         HIP_TRY(hipEventCreate(&ev), "hipEventCreate");
@@ -1175,6 +1242,25 @@ int racc_hip_intersect_device_timed(racc_hip_ctx* ctx, const racc_hip_scene* sce
         HIP_TRY(hipEventElapsedTime(&ms[i], l.events[2 * i], l.events[2 * i + 1]), "hipEventElapsedTime");
     l.info.last_kernel_ms = ms[iters - 1];
     return checkWatchdog(ctx);
+}
+
+int racc_hip_read_kernel_times(racc_hip_ctx* ctx, uint32_t lane, float* ms, uint32_t capacity, uint32_t* n) {
+    if (int rc = checkLane(ctx, lane)) return rc;
+    if (!n || (capacity && !ms)) return fail(RACC_HIP_ERR_INVALID, "read_kernel_times: bad argument");
+    *n = 0;
+    if (!ctx->opts.time_kernels) return fail(RACC_HIP_ERR_INVALID, "read_kernel_times: the context was created without time_kernels");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    Lane& l = ctx->lanes[lane];
+    std::lock_guard<std::mutex> guard(l.mutex);
+    const uint32_t have = l.ringCount < capacity ? l.ringCount : capacity;
+    for (uint32_t i = 0; i < have; ++i) {                     // oldest of the most recent `have` first
+        const uint32_t slot = (l.ringHead + kTimeRing - have + i) % kTimeRing;
+        HIP_TRY(hipEventSynchronize(l.ring[2 * slot + 1]), "hipEventSynchronize");
+        HIP_TRY(hipEventElapsedTime(&ms[i], l.ring[2 * slot], l.ring[2 * slot + 1]), "hipEventElapsedTime");
+    }
+    *n = have;
+    l.ringCount = 0;
+    return RACC_HIP_OK;
 }
 
 int racc_hip_get_launch_info(racc_hip_ctx* ctx, uint32_t lane, racc_hip_launch_info* info) {
@@ -1209,6 +1295,29 @@ int racc_hip_free(racc_hip_ctx* ctx, void* d_ptr) {
     return RACC_HIP_OK;
 }
 
+int racc_hip_stream_create(racc_hip_ctx* ctx, void** stream) {
+    if (!ctx || !stream) return fail(RACC_HIP_ERR_INVALID, "stream_create: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+    *stream = st;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_stream_synchronize(racc_hip_ctx* ctx, void* stream) {
+    if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize");
+    return checkWatchdog(ctx);
+}
+
+int racc_hip_stream_destroy(racc_hip_ctx* ctx, void* stream) {
+    if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    if (stream) HIP_TRY(hipStreamDestroy(static_cast<hipStream_t>(stream)), "hipStreamDestroy");
+    return RACC_HIP_OK;
+}
+
 int racc_hip_memcpy_h2d(racc_hip_ctx* ctx, void* d_dst, const void* src, uint64_t bytes) {
     if (!ctx || !d_dst || !src) return fail(RACC_HIP_ERR_INVALID, "memcpy_h2d: bad argument");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
@@ -1220,6 +1329,89 @@ int racc_hip_memcpy_d2h(racc_hip_ctx* ctx, void* dst, const void* d_src, uint64_
     if (!ctx || !dst || !d_src) return fail(RACC_HIP_ERR_INVALID, "memcpy_d2h: bad argument");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H");
+    return RACC_HIP_OK;
+}
+
+// ---- RCCL (librccl, = NCCL's API over xGMI), bound at run time: the engine itself has no link dependency on it ----------
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    int (*getUniqueId)(void*) = nullptr;
+    int (*commInitRank)(void**, int, racc_hip_comm_id, int) = nullptr;
+    int (*allGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*commDestroy)(void*) = nullptr;
+    const char* (*errorString)(int) = nullptr;
+};
+RcclApi* rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy the process already loaded (torch.distributed ships its own) first, then the ROCm one
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!api.lib) return;
+        api.getUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(api.lib, "ncclGetUniqueId"));
+        api.commInitRank = reinterpret_cast<int (*)(void**, int, racc_hip_comm_id, int)>(dlsym(api.lib, "ncclCommInitRank"));
+        api.allGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(api.lib, "ncclAllGather"));
+        api.commDestroy = reinterpret_cast<int (*)(void*)>(dlsym(api.lib, "ncclCommDestroy"));
+        api.errorString = reinterpret_cast<const char* (*)(int)>(dlsym(api.lib, "ncclGetErrorString"));
+    });
+    return (api.lib && api.getUniqueId && api.commInitRank && api.allGather && api.commDestroy) ? &api : nullptr;
+}
+int failRccl(const char* what, int rc) {
+    RcclApi* r = rccl();
+    snprintf(g_msg, sizeof(g_msg), "racc_hip: %s: %s", what, r && r->errorString ? r->errorString(rc) : "librccl not available");
+    racc_hip_set_error_(g_msg);
+    return RACC_HIP_ERR_DEVICE;
+}
+}  // namespace
+
+struct racc_hip_comm {
+    racc_hip_ctx* ctx = nullptr;
+    void* comm = nullptr;          // ncclComm_t
+    int rank = 0, nranks = 1;
+};
+
+int racc_hip_comm_unique_id(racc_hip_comm_id* id) {
+    if (!id) return fail(RACC_HIP_ERR_INVALID, "id is NULL");
+    RcclApi* r = rccl();
+    if (!r) return failRccl("ncclGetUniqueId", 0);
+    if (int rc = r->getUniqueId(id)) return failRccl("ncclGetUniqueId", rc);
+    return RACC_HIP_OK;
+}
+
+int racc_hip_comm_init_rank(racc_hip_ctx* ctx, const racc_hip_comm_id* id, int rank, int nranks, racc_hip_comm** out) {
+    if (!ctx || !id || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail(RACC_HIP_ERR_INVALID, "comm_init_rank: bad argument");
+    *out = nullptr;
+    RcclApi* r = rccl();
+    if (!r) return failRccl("ncclCommInitRank", 0);
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    racc_hip_comm* c = new (std::nothrow) racc_hip_comm();
+    if (!c) return fail(RACC_HIP_ERR_NOMEM, "out of host memory");
+    c->ctx = ctx; c->rank = rank; c->nranks = nranks;
+    if (int rc = r->commInitRank(&c->comm, nranks, *id, rank)) { delete c; return failRccl("ncclCommInitRank", rc); }
+    *out = c;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_allgather_results(racc_hip_comm* comm, const void* d_send, void* d_recv, uint32_t count_per_rank, void* stream) {
+    if (!comm || !d_send || !d_recv) return fail(RACC_HIP_ERR_INVALID, "allgather_results: bad argument");
+    if (!count_per_rank) return RACC_HIP_OK;
+    RcclApi* r = rccl();
+    if (!r) return failRccl("ncclAllGather", 0);
+    HIP_TRY(hipSetDevice(comm->ctx->device), "hipSetDevice");
+    // a Result is 16 bytes = 4 x u32 (ncclUint32 = 3); one message per rank, as large as the shard (ring collectives over
+    // point-to-point xGMI are per-link bound: few large messages, never one per ray stream)
+    if (int rc = r->allGather(d_send, d_recv, size_t(count_per_rank) * 4u, 3, comm->comm, static_cast<hipStream_t>(stream))) return failRccl("ncclAllGather", rc);
+    return RACC_HIP_OK;
+}
+
+int racc_hip_comm_destroy(racc_hip_comm* comm) {
+    if (!comm) return RACC_HIP_OK;
+    RcclApi* r = rccl();
+    if (r && comm->comm) { hipSetDevice(comm->ctx->device); r->commDestroy(comm->comm); }
+    delete comm;
     return RACC_HIP_OK;
 }
 

@@ -41,7 +41,7 @@ class RaccError(RuntimeError):
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("lanes", C.c_uint32), ("waves_per_simd", C.c_uint32),
                 ("kernel_variant", C.c_uint32), ("refill_min", C.c_uint32), ("leaf_min", C.c_uint32),
-                ("chunk", C.c_uint32), ("tail_active", C.c_uint32), ("regroup_period", C.c_uint32), ("thin_reps", C.c_uint32), ("inner_reps", C.c_uint32), ("coop_same_pct", C.c_uint32), ("reserved", C.c_uint32 * 4)]
+                ("chunk", C.c_uint32), ("tail_active", C.c_uint32), ("regroup_period", C.c_uint32), ("thin_reps", C.c_uint32), ("inner_reps", C.c_uint32), ("coop_same_pct", C.c_uint32), ("time_kernels", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
 class SceneInfo(C.Structure):
@@ -81,12 +81,20 @@ ABI = {
     "racc_hip_intersect_device": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "racc_hip_intersect_device_timed": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _P(C.c_float)]),
     "racc_hip_get_launch_info": (_i, [_vp, _u32, _P(LaunchInfo)]),
+    "racc_hip_read_kernel_times": (_i, [_vp, _u32, _P(C.c_float), _u32, _P(_u32)]),
     "racc_hip_read_stats": (_i, [_vp, _u32, _P(_u64), _i]),
     "racc_hip_malloc": (_i, [_vp, _u64, _P(_vp)]),
     "racc_hip_free": (_i, [_vp, _vp]),
     "racc_hip_memcpy_h2d": (_i, [_vp, _vp, _vp, _u64]),
     "racc_hip_memcpy_d2h": (_i, [_vp, _vp, _vp, _u64]),
     "racc_hip_synchronize": (_i, [_vp]),
+    "racc_hip_stream_create": (_i, [_vp, _P(_vp)]),
+    "racc_hip_stream_synchronize": (_i, [_vp, _vp]),
+    "racc_hip_stream_destroy": (_i, [_vp, _vp]),
+    "racc_hip_comm_unique_id": (_i, [_vp]),
+    "racc_hip_comm_init_rank": (_i, [_vp, _vp, _i, _i, _P(_vp)]),
+    "racc_hip_allgather_results": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "racc_hip_comm_destroy": (_i, [_vp]),
     "racc_host_scene_build": (_i, [_vp, _u32, _vp, _u32, _P(_vp)]),
     "racc_host_scene_free": (_i, [_vp]),
     "racc_host_scene_blobs": (_i, [_vp, _P(_vp), _P(_u32), _P(_vp), _P(_u32), _P(_u32), _P(_vp), _P(_u32)]),
@@ -240,10 +248,13 @@ class DeviceBuffer:
             self.ptr = None
 
 
+LANE_AUTO = 0xFFFFFFFF      # RACC_HIP_LANE_AUTO
+
+
 class Context:
     """≙ racc::Context for the GPU intersect path; one per (process, GPU)."""
 
-    def __init__(self, device=0, lanes=0, waves_per_simd=0, refill_min=0, leaf_min=0, chunk=0, kernel_variant=0, tail_active=0, regroup_period=0, thin_reps=0, inner_reps=0, coop_same_pct=0):
+    def __init__(self, device=0, lanes=0, waves_per_simd=0, refill_min=0, leaf_min=0, chunk=0, kernel_variant=0, tail_active=0, regroup_period=0, thin_reps=0, inner_reps=0, coop_same_pct=0, time_kernels=0):
         lib = load_library()
         o = Options()
         o.struct_size = C.sizeof(Options)
@@ -251,6 +262,8 @@ class Context:
         o.tail_active, o.regroup_period, o.thin_reps = tail_active, regroup_period, thin_reps
         o.inner_reps = inner_reps
         o.coop_same_pct = coop_same_pct
+        o.time_kernels = time_kernels
+        self.lanes = lanes or 4
         h = C.c_void_p()
         _check(lib.racc_hip_create(device, C.byref(o), C.byref(h)))
         self._h = h
@@ -322,6 +335,24 @@ class Context:
     def wait(self, lane=0):
         _check(load_library().racc_hip_wait(self._h, lane))
 
+    def create_stream(self):
+        st = C.c_void_p()
+        _check(load_library().racc_hip_stream_create(self._h, C.byref(st)))
+        return st.value
+
+    def stream_synchronize(self, stream):
+        _check(load_library().racc_hip_stream_synchronize(self._h, stream))
+
+    def destroy_stream(self, stream):
+        _check(load_library().racc_hip_stream_destroy(self._h, stream))
+
+    def kernel_times(self, lane=0, capacity=256):
+        """Durations (ms) of the lane's traversal kernels since the last call (Context(time_kernels=1))."""
+        ms = (C.c_float * capacity)()
+        n = C.c_uint32(0)
+        _check(load_library().racc_hip_read_kernel_times(self._h, lane, ms, capacity, C.byref(n)))
+        return list(ms[:n.value])
+
     def synchronize(self):
         _check(load_library().racc_hip_synchronize(self._h))
 
@@ -339,6 +370,30 @@ class Context:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+
+class Comm:
+    """RCCL communicator over the GPUs of one node, bound through the C-ABI (racc_hip_comm_*): all-gather of Result shards."""
+
+    def __init__(self, ctx, unique_id, rank, nranks):
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _check(load_library().racc_hip_comm_init_rank(ctx._h, buf, rank, nranks, C.byref(h)))
+        self._h, self.rank, self.nranks = h, rank, nranks
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(load_library().racc_hip_comm_unique_id(buf))
+        return buf.raw
+
+    def allgather_results(self, d_send, d_recv, count_per_rank, stream=None):
+        _check(load_library().racc_hip_allgather_results(self._h, d_send, d_recv, count_per_rank, stream))
+
+    def destroy(self):
+        if self._h:
+            load_library().racc_hip_comm_destroy(self._h)
+            self._h = None
 
 
 class PathTraceStats(C.Structure):

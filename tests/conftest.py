@@ -41,3 +41,17 @@ def gpu_ctx():
     ctx = rayaccel_amd.Context(device=0)     # raises (never falls back) when the extension or GPU is missing
     yield ctx
     ctx.destroy()
+
+
+@pytest.fixture(scope="session")
+def full(gpu_ctx):
+    """battlefield-synth at full size (1.07 M triangles) on the GPU, with the 1M-ray coherent primary batch."""
+    import rayaccel_amd as ra
+    from rayaccel_amd import synth
+    sc = synth.battlefield_synth()
+    host = ra.HostScene(sc["vertices"], sc["indices"])
+    scene = gpu_ctx.upload_scene(host.nodes, host.pairs, host.remap)
+    env = gpu_ctx.create_environment(sc["env"])
+    prim, _ = synth.primary_rays(sc["camera"], 1024, 1024)
+    yield dict(sc=sc, host=host, blobs=host.blobs(), scene=scene, env=env, primary=prim)
+    scene.destroy(); env.destroy()

@@ -135,7 +135,20 @@ int main(int argc, char** argv) {
     }
 
     racc::init();
-    racc::GpuContext gpu = racc::gpuContextForDevice(0);
+    // RACC_DEVICES=0,0 (or 0,1,...): one racc::Context over several engine contexts, scene replicated, streams sharded
+    racc::GpuContext gpu = nullptr;
+    if (const char* d = std::getenv("RACC_DEVICES")) {
+        int ordinals[RACC_MAX_DEVICES];
+        unsigned n = 0;
+        for (const char* p = d; *p && n < RACC_MAX_DEVICES;) {
+            ordinals[n++] = std::atoi(p);
+            while (*p && *p != ',') ++p;
+            if (*p == ',') ++p;
+        }
+        gpu = racc::gpuContextForDevices(ordinals, n);
+    } else {
+        gpu = racc::gpuContextForDevice(0);
+    }
     racc::Configuration cfg = racc::defaultConfiguration(gpu);
     if (const char* t = std::getenv("RACC_CPU_THREADS")) cfg.cpuThreads = unsigned(std::atoi(t));
     if (const char* t = std::getenv("RACC_BATCH")) cfg.rayStreamBatchSize = unsigned(std::atoi(t));
@@ -157,6 +170,7 @@ int main(int argc, char** argv) {
         app.nextTile = 0;
         for (auto& v : app.perThread) v.clear();
         traced = racc::render(ctx, scene, environment, cb).raysTraced;
+        if (const char* err = racc::lastError(ctx)) { std::fprintf(stderr, "render_check: %s\n", err); return 5; }
     }
     uint64_t count = 0;
     for (auto& v : app.perThread) count += v.size();

@@ -16,7 +16,8 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 def _line(cmd, env=None):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip() and not l.startswith("[Gloo]")]      # gloo's own chatter (rehearsal only)
+    # gloo's own chatter (rehearsal only; two ranks interleave it, so a fragment may lack the "[Gloo]" prefix)
+    lines = [l for l in p.stdout.splitlines() if l.strip() and not l.startswith("[Gloo]") and "connected peer ranks" not in l]
     assert len(lines) == 1, "bench must print exactly one line on stdout: %r" % lines[-3:]
     return json.loads(lines[0])
 

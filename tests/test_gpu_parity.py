@@ -188,17 +188,6 @@ def test_order_independence_and_split_batches(gpu_ctx, small):
 
 
 # ---------------------------------------------------------------- BASELINE.json full sizes
-@pytest.fixture(scope="module")
-def full(gpu_ctx):
-    sc = synth.battlefield_synth()
-    host = ra.HostScene(sc["vertices"], sc["indices"])
-    scene = gpu_ctx.upload_scene(host.nodes, host.pairs, host.remap)
-    env = gpu_ctx.create_environment(sc["env"])
-    prim, _ = synth.primary_rays(sc["camera"], 1024, 1024)
-    yield dict(sc=sc, host=host, scene=scene, env=env, primary=prim)
-    scene.destroy(); env.destroy()
-
-
 def test_full_size_1M_coherent_and_diffuse(gpu_ctx, full):
     """BASELINE configs[1] and [2] at full size: bit-exact vs the oracle (it finishes in ~1 s per batch)
     plus size-independent properties."""
@@ -346,3 +335,79 @@ def test_soak_random_options_sizes_and_lanes():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_fuzz.py"), "16", "11"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_lane_auto_rotation(gpu_ctx, small):
+    """RACC_HIP_LANE_AUTO: a single-threaded caller issues batch after batch, the engine rotates them over its lanes (their
+    launches overlap on the GPU), one wait for all.  Every batch bit-exact."""
+    batches = _batches(small)
+    names = list(batches) * 3
+    outs = []
+    for k in names:
+        rays = batches[k]
+        d_r = gpu_ctx.alloc(rays.nbytes); d_o = gpu_ctx.alloc(len(rays) * 16); d_r.upload(rays)
+        gpu_ctx.intersect_device(small["scene"], small["env"], d_r.ptr, d_o.ptr, len(rays), lane=ra.LANE_AUTO)
+        outs.append((k, d_r, d_o, len(rays)))
+    gpu_ctx.wait(ra.LANE_AUTO)
+    refs = {k: orc.traverse(small["blobs"], batches[k], env=small["sc"]["env"]) for k in batches}
+    for k, d_r, d_o, n in outs:
+        assert_bit_exact(d_o.download(orc.RESULT_DTYPE, n), refs[k], "auto lane " + k)
+        d_r.free(); d_o.free()
+
+
+def test_one_lane_from_two_caller_streams(gpu_ctx, small):
+    """A lane owns one ray cursor: two launches on the SAME lane from two different caller streams used to race on it
+    (ADVICE r1).  The engine now makes the second wait for the first on the device; both must be exact, many times over."""
+    s1, s2 = gpu_ctx.create_stream(), gpu_ctx.create_stream()
+    batches = _batches(small)
+    a, b = batches["diffuse"], batches["random"]
+    ref_a = orc.traverse(small["blobs"], a, env=small["sc"]["env"]); ref_b = orc.traverse(small["blobs"], b, env=small["sc"]["env"])
+    bufs = []
+    for rays in (a, b):
+        d_r = gpu_ctx.alloc(rays.nbytes); d_o = gpu_ctx.alloc(len(rays) * 16); d_r.upload(rays)
+        bufs.append((d_r, d_o, len(rays)))
+    for rnd in range(6):
+        gpu_ctx.intersect_device(small["scene"], small["env"], bufs[0][0].ptr, bufs[0][1].ptr, bufs[0][2], lane=1, stream=s1)
+        gpu_ctx.intersect_device(small["scene"], small["env"], bufs[1][0].ptr, bufs[1][1].ptr, bufs[1][2], lane=1, stream=s2)
+        gpu_ctx.intersect_device(small["scene"], small["env"], bufs[0][0].ptr, bufs[0][1].ptr, bufs[0][2], lane=1)      # and the lane's own stream
+        gpu_ctx.stream_synchronize(s1); gpu_ctx.stream_synchronize(s2); gpu_ctx.wait(1)
+        assert_bit_exact(bufs[0][1].download(orc.RESULT_DTYPE, bufs[0][2]), ref_a, "two streams, round %d (a)" % rnd)
+        assert_bit_exact(bufs[1][1].download(orc.RESULT_DTYPE, bufs[1][2]), ref_b, "two streams, round %d (b)" % rnd)
+    for d_r, d_o, _ in bufs:
+        d_r.free(); d_o.free()
+    gpu_ctx.destroy_stream(s1); gpu_ctx.destroy_stream(s2)
+
+
+def test_config3_8M_rays_in_8_shards(gpu_ctx, full):
+    """BASELINE configs[3] at full size on one GPU: 8,388,608 first-bounce diffuse rays (8 sample sets), once as ONE launch and
+    once as the 8 contiguous shards the 8 ranks of a node take (rayaccel_amd.shard.shard_range): the concatenation must be the
+    single launch bit for bit, a 1 % sample of it bit-exact against the oracle, and the shards must gather (RCCL all-gather
+    entry of the C-ABI, one rank here) into the same buffer."""
+    from rayaccel_amd.shard import shard_range
+    sc, blobs = full["sc"], full["blobs"]
+    hits = gpu_ctx.intersect(full["scene"], full["env"], full["primary"])
+    rays = np.concatenate([synth.diffuse_bounce_rays(sc, full["primary"], hits, 1 << 20, first_sample=k) for k in range(8)])
+    n = len(rays)
+    assert n == 8 << 20
+    d_r = gpu_ctx.alloc(rays.nbytes); d_all = gpu_ctx.alloc(n * 16); d_sh = gpu_ctx.alloc(n * 16); d_r.upload(rays)
+    gpu_ctx.intersect_device(full["scene"], full["env"], d_r.ptr, d_all.ptr, n)
+    gpu_ctx.wait(0)
+    whole = d_all.download(orc.RESULT_DTYPE, n)
+    for r in range(8):
+        b, e = shard_range(n, r, 8)
+        gpu_ctx.intersect_device(full["scene"], full["env"], d_r.ptr + b * 32, d_sh.ptr + b * 16, e - b, lane=ra.LANE_AUTO)
+    gpu_ctx.wait(ra.LANE_AUTO)
+    sharded = d_sh.download(orc.RESULT_DTYPE, n)
+    assert sharded.tobytes() == whole.tobytes()
+    pick = np.random.default_rng(3).choice(n, n // 100, replace=False)
+    assert_bit_exact(whole[pick], orc.traverse(blobs, np.ascontiguousarray(rays[pick]), env=sc["env"], threads=8), "8M, 1 % sample")
+    assert 0.5 < (whole["triangle"] != MISS).mean() < 0.8
+    # the C-ABI's RCCL entry (world of one rank: the gather is the identity; N ranks run it unchanged)
+    comm = ra.Comm(gpu_ctx, ra.Comm.unique_id(), 0, 1)
+    d_g = gpu_ctx.alloc(n * 16)
+    comm.allgather_results(d_sh.ptr, d_g.ptr, n)
+    gpu_ctx.synchronize()
+    assert d_g.download(orc.RESULT_DTYPE, n).tobytes() == whole.tobytes()
+    comm.destroy()
+    for d in (d_r, d_all, d_sh, d_g):
+        d.free()

@@ -68,6 +68,19 @@ def test_device_consumer_renders_the_same_image(scene_file):
     assert np.array_equal(lo + hi, gpu)
 
 
+def test_config4_1080p_device_and_host_consumer_render_the_same_frame(tmp_path, full):
+    """BASELINE configs[4] at full size: battlefield-synth, 1920x1080 (15x8 whole tiles, as TiledRenderer.cpp:20-22 renders),
+    4 spp, depth from the scene header — the device-resident consumer against the reference-shaped host consumer: identical
+    fixed-point frames and ray counts.  (64 spp is the same code 16 times over; bench.py times it.)"""
+    p = os.path.join(str(tmp_path), "full.bin")
+    synth.write_scene_bin(p, full["sc"], viewport=(1920, 1080))
+    g, sg = path_trace(p, 1920, 1080, 0, 4, shading="gpu")
+    c, sc_ = path_trace(p, 1920, 1080, 0, 4, shading="cpu")
+    assert sg["primary_rays"] == sc_["primary_rays"] == 4 * 15 * 8 * 128 * 128
+    assert sg["rays_traced"] == sc_["rays_traced"] > 2 * sg["primary_rays"]
+    assert np.array_equal(g, c) and g[:1024].any() and not g[1024:].any()
+
+
 def test_device_consumer_whole_tiles(scene_file):
     img, st = path_trace(scene_file, 300, 200, 0, 2, shading="gpu")
     assert (st["tiles_x"], st["tiles_y"]) == (2, 1) and st["primary_rays"] == 2 * 2 * 128 * 128 and st["threads"] == 0

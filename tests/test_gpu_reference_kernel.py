@@ -18,15 +18,19 @@ from helpers import MISS, comb_scene, make_rays
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_kernel.built(), reason="oracle/_ref not built (needs /root/reference at build time)")]
 
 
-def _compare(ref, other, what, rel=1e-4):
+def _compare(ref, other, what, rel=1e-4, max_ties=None):
+    """The reference's kernel is built with its own fast-math options (RayAccelerator.cpp:489-490), so it is compared within
+    north_star's tolerance: NO hit/miss disagreement is accepted; a different primId only as a tie (both report the same
+    distance to 1e-5: coplanar or edge-sharing triangles, the later test wins in one arithmetic and not in the other)."""
     n = len(ref)
     hit_r, hit_o = ref["triangle"] != MISS, other["triangle"] != MISS
-    assert (hit_r != hit_o).sum() <= max(1, n // 100000), "%s: %d hit/miss disagreements" % (what, (hit_r != hit_o).sum())
+    disagreements = int((hit_r != hit_o).sum())
     both = hit_r & hit_o
     diff = both & (ref["triangle"] != other["triangle"])
-    # a different primId is only acceptable as a tie: both report the same distance
+    print("%s: %d rays, %d hit/miss disagreements, %d primId ties" % (what, n, disagreements, int(diff.sum())))
+    assert disagreements == 0, "%s: %d hit/miss disagreements" % (what, disagreements)
     assert np.allclose(ref["t"][diff], other["t"][diff], rtol=1e-5), "%s: %d primId mismatches that are not ties" % (what, diff.sum())
-    assert diff.sum() <= max(2, n // 20000), "%s: %d ties" % (what, diff.sum())
+    assert diff.sum() <= (max(2, n // 20000) if max_ties is None else max_ties), "%s: %d ties" % (what, diff.sum())
     same = both & ~diff
     np.testing.assert_allclose(other["t"][same], ref["t"][same], rtol=rel, err_msg=what)
     np.testing.assert_allclose(other["u"][same], ref["u"][same], rtol=rel, atol=2e-6, err_msg=what)
@@ -69,4 +73,4 @@ def test_full_size_batch_against_the_reference_kernel(gpu_ctx):
     scene = gpu_ctx.upload_scene(host.nodes, host.pairs, host.remap)
     _compare(reference, gpu_ctx.intersect(scene, None, bounce), "HIP engine vs reference kernel, 1M diffuse")
     scene.destroy()
-    assert ties <= 50
+    assert ties <= 4           # observed on the MI355X: 0 (printed above)

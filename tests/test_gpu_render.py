@@ -57,6 +57,53 @@ def test_render_matches_oracle(tmp_path, small_scene, small_host, cfg):
         np.testing.assert_allclose(got[f][~hit], ref[f][~hit], rtol=1e-5, atol=1e-5)
 
 
+def _check_against_oracle(recs, blobs, env):
+    ref = orc.traverse(blobs, np.ascontiguousarray(recs["ray"]), env=env, threads=8)
+    got = np.ascontiguousarray(recs["res"])
+    assert np.array_equal(got["triangle"], ref["triangle"])
+    hit = ref["triangle"] != MISS
+    for f in ("t", "u", "v"):
+        assert np.array_equal(got[f][hit].view(np.uint32), ref[f][hit].view(np.uint32))
+        np.testing.assert_allclose(got[f][~hit], ref[f][~hit], rtol=1e-5, atol=1e-5)
+    return ref
+
+
+def test_one_context_over_two_engine_contexts(tmp_path, small_scene, small_host):
+    """Multi-device behind the boundary (racc::gpuContextForDevices), rehearsed on the one GPU of the test box with the entry
+    list 0,0: two engine contexts, scene and environment replicated, ray streams sharded over them as whole streams.  Same
+    rays, same results, none lost or duplicated."""
+    info, recs = _run(str(tmp_path), small_scene, 512, 384, 3, frames=2, env=dict(RACC_DEVICES="0,0", RACC_BATCH="8192"))
+    info1, recs1 = _run(str(tmp_path), small_scene, 512, 384, 3, frames=2, env=dict(RACC_BATCH="8192"))
+    assert len(recs) == len(recs1)
+    _check_against_oracle(recs, small_host.blobs(), small_scene["env"])
+    key = lambda r: np.lexsort((r["ray"]["dir"][:, 2], r["ray"]["dir"][:, 0], r["depth"], r["pixel"]))
+    a, b = recs[key(recs)], recs1[key(recs1)]
+    assert a.tobytes() == b.tobytes()              # the same set of (pixel, depth, ray, result) records as with one engine context
+
+
+def test_config0_64k_primary_rays_on_the_full_scene(tmp_path, full):
+    """BASELINE configs[0]: battlefield-synth (1.07 M triangles), 256x256 pinhole-coherent primary rays through racc::render
+    (spawn tiles of 128x128 as TiledRenderer.cpp:55-67 does; the reference runs this config on its CPU path, which needs Embree —
+    here the same plumbing feeds the GPU).  Every ray re-traced by the oracle."""
+    sc = full["sc"]
+    info, recs = _run(str(tmp_path), sc, 256, 256, 1, frames=1)
+    assert len(recs) == 65536 and info["raysTraced"] == 65536
+    assert np.array_equal(np.sort(recs["pixel"]), np.arange(65536, dtype=np.uint32))
+    ref = _check_against_oracle(recs, full["blobs"], sc["env"])
+    assert (ref["triangle"] != MISS).mean() > 0.3
+
+
+def test_config4_1080p_ray_streams_retraced_by_the_oracle(tmp_path, full):
+    """BASELINE configs[4]'s ray streams at full size: 1920x1080 primaries (15x8 tiles = 1,966,080 rays) plus their first
+    bounce through racc::render on battlefield-synth; every one of the ~3 M traced rays re-traced by the oracle."""
+    sc = full["sc"]
+    info, recs = _run(str(tmp_path), sc, 1920, 1080, 2, frames=1)
+    prim = recs[recs["depth"] == 0]
+    assert len(prim) == 15 * 8 * 128 * 128
+    assert int((recs["depth"] == 1).sum()) == int((prim["res"]["triangle"] != MISS).sum()) > 500000
+    _check_against_oracle(recs, full["blobs"], sc["env"])
+
+
 def test_create_context_without_gpu_context_fails_loudly(tmp_path):
     src = os.path.join(str(tmp_path), "t.cpp")
     open(src, "w").write('#include "RayAccelerator.h"\nint main(){ racc::init(); racc::Configuration c = racc::defaultConfiguration(nullptr);'
