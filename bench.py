@@ -5,12 +5,19 @@ A "step" is one pass of the path over one batch: 1,048,576 first-bounce diffuse
 (incoherent) rays on the battlefield-synth stand-in scene per GPU (BASELINE.json
 configs[2]; at N GPUs every rank traces its own 1M-ray batch = configs[3]'s 8M rays at
 N=8, weak scaling, no data-path collective — rays never interact).  Inputs are resident
-in HBM before the timed region.  Output: ONE JSON line on rank 0 (see README/DESIGN.md).
+in HBM before the timed region.  The K steps are issued the way a caller of the C-ABI
+issues batch after batch: racc_hip_intersect_device(lane = RACC_HIP_LANE_AUTO), i.e. the
+engine rotates them over its lanes (≙ the reference's gpuSubmissionThreads queues,
+RayAccelerator.cpp:711-717) and one step's drain runs under the next one's bulk; the
+timed region ends when every step's results are in HBM.  Output: ONE JSON line on rank 0.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    ... bench.py --mode strong      # BASELINE configs[3] as written: ONE 8M-ray batch cut into N contiguous shards,
+                                    # second figure with the RCCL all-gather of the hit records inside the timed region
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -23,16 +30,29 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI35
 HBM_MEASURED_GBS = 6290.0      # same guide: float4-copy ceiling
 RAYS_PER_BATCH = 1 << 20
 KERNEL_NAME = "traverseKernelV8"
+PROFILE_DIR = os.path.join("profiles", "r02")      # rocprofv3 summaries of THIS command (tools/profile_bench.sh r02)
+KERNEL_SOURCES = ("rayaccel_amd/csrc/racc_hip.hip", "rayaccel_amd/csrc/racc_device.inc")
 
 
-def _committed_traffic():
-    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (or None)."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def kernel_source_sha256():
+    """Hash of the files the traversal kernel is compiled from; the committed profile records the one it was taken with."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def committed_profile():
+    """Derived figures of the rocprofv3 passes committed under profiles/ (tools/summarize_profile.py), or None.
+    Marked stale when the kernel sources changed since: the numbers then describe another kernel."""
     try:
-        with open(path) as f:
-            return json.load(f)
+        with open(os.path.join(ROOT, PROFILE_DIR, "derived.json")) as f:
+            d = json.load(f)
     except (OSError, ValueError):
         return None
+    d["stale"] = d.get("kernel_source_sha256") != kernel_source_sha256()
+    return d
 
 
 def usable_cores():
@@ -59,6 +79,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=("weak", "strong"), default="weak",
+                    help="weak (default): 1M rays per GPU per step; strong: one 8M-ray batch per step cut into N shards (configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (profiling runs)")
     ap.add_argument("--grid", type=int, default=700, help="height-field resolution of battlefield-synth (700 = full)")
@@ -79,6 +101,7 @@ def main():
 
     import rayaccel_amd as ra
     from rayaccel_amd import synth
+    from rayaccel_amd.shard import shard_range
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
@@ -102,78 +125,105 @@ def main():
     full = args.grid == 700
     sc = synth.battlefield_synth() if full else synth.battlefield_synth(grid=args.grid, boxes=args.grid * 6, quads=args.grid * 28)
     host = ra.HostScene(sc["vertices"], sc["indices"])
-    engine_opts = json.loads(args.engine_opts) if args.engine_opts else {}
+    engine_opts = dict(lanes=4, time_kernels=1)
+    engine_opts.update(json.loads(args.engine_opts) if args.engine_opts else {})
     ctx = ra.Context(device=device, **engine_opts)
+    lanes = ctx.lanes
     scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
     env = ctx.create_environment(sc["env"])
 
     primary, _ = synth.primary_rays(sc["camera"], 1024, 1024)
     primary_hits = ctx.intersect(scene, env, primary)                       # GPU path, host buffers
-    bounce = synth.diffuse_bounce_rays(sc, primary, primary_hits, RAYS_PER_BATCH, first_sample=rank)
+    if args.mode == "weak":
+        bounce = synth.diffuse_bounce_rays(sc, primary, primary_hits, RAYS_PER_BATCH, first_sample=rank)
+        total_rays = world * len(bounce)
+    else:       # strong: configs[3], 8 sample sets = one 8M-ray batch; this rank's contiguous shard of it
+        whole = np.concatenate([synth.diffuse_bounce_rays(sc, primary, primary_hits, RAYS_PER_BATCH, first_sample=k) for k in range(8)])
+        total_rays = len(whole)
+        b, e = shard_range(total_rays, rank, world)
+        bounce = np.ascontiguousarray(whole[b:e])
+        del whole
     n = len(bounce)
 
     d_rays = torch.from_numpy(bounce.view(np.float32).reshape(n, 8).copy()).cuda()
-    d_out = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    outs = [torch.zeros((n, 4), dtype=torch.float32, device="cuda") for _ in range(lanes)]      # one per lane: launches overlap
+    d_out = outs[0]
     torch.cuda.synchronize()
 
-    def run(iters, rays_t=d_rays, out_t=d_out):
-        return ctx.intersect_device_timed(scene, env, rays_t.data_ptr(), out_t.data_ptr(), rays_t.shape[0], iters)
+    def run_overlapped(steps):
+        """`steps` batches, issued like a caller of the C-ABI issues them: the engine rotates the lanes."""
+        for k in range(steps):
+            ctx.intersect_device(scene, env, d_rays.data_ptr(), outs[k % lanes].data_ptr(), n, lane=ra.LANE_AUTO)
+        ctx.wait(ra.LANE_AUTO)
+
+    def drain_kernel_times():
+        return [t for lane in range(lanes) for t in ctx.kernel_times(lane)]
 
     if args.warmup:
-        run(args.warmup)
+        run_overlapped(args.warmup)
+    drain_kernel_times()
 
     # ---- timed region: exactly K steps, barrier + device sync on both sides --------------------
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kernel_ms = run(args.steps)          # K back-to-back launches, a HIP event pair around each, on the launch stream
+    run_overlapped(args.steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+    kernel_ms = drain_kernel_times()            # HIP events around each traversal kernel, on the stream it ran on
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    value = world * n * args.steps / elapsed / 1e6
+    value = total_rays * args.steps / elapsed / 1e6
     launch = ctx.launch_info()
 
     # ---- optional extras, all outside the timed region ------------------------------------------
     extras = {}
-    if world > 1 and backend == "nccl":   # RCCL all-gather of the Result shards over xGMI (only needed by a GPU-side consumer)
-        gathered = torch.empty((world * n, 4), dtype=torch.float32, device="cuda")
-        dist.all_gather_into_tensor(gathered, d_out)
+    if world > 1 and backend == "nccl":
+        # RCCL all-gather of the Result shards over xGMI through the C-ABI's own entry (racc_hip_allgather_results binds
+        # librccl; only a GPU-side consumer that needs every hit on every GPU needs it).  Second timed figure: the same K
+        # steps with the gather of every step's results inside the region.
+        uid = [ra.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = ra.Comm(ctx, uid[0], rank, world)
+        per = -(-total_rays // world) if args.mode == "strong" else n
+        gathered = torch.empty((world * per, 4), dtype=torch.float32, device="cuda")
+        send = torch.zeros((per, 4), dtype=torch.float32, device="cuda")
+        comm.allgather_results(send.data_ptr(), gathered.data_ptr(), per)
         torch.cuda.synchronize(); barrier()
         t1 = time.perf_counter()
-        for _ in range(5):
-            dist.all_gather_into_tensor(gathered, d_out)
-        torch.cuda.synchronize()
-        extras["allgather_results_ms"] = round((time.perf_counter() - t1) / 5 * 1e3, 4)
-        extras["allgather_bytes"] = int(gathered.numel() * 4)
+        for k in range(args.steps):
+            lane = k % lanes
+            ctx.intersect_device(scene, env, d_rays.data_ptr(), send.data_ptr(), n, lane=lane)
+            ctx.wait(lane)
+            comm.allgather_results(send.data_ptr(), gathered.data_ptr(), per)
+        ctx.synchronize(); torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        extras["with_allgather_of_results"] = {"mrays_per_s": round(total_rays * args.steps / float(dt.item()) / 1e6, 1),
+                                               "ms_per_step": round(float(dt.item()) / args.steps * 1e3, 4),
+                                               "bytes_gathered_per_step": int(gathered.numel() * 4),
+                                               "how": "racc_hip_allgather_results (C-ABI -> ncclAllGather), one message per rank, trace and gather serialised per step"}
+        comm.destroy()
     if rank == 0 and not args.no_extras:
+        def timed_serial(rays_t, out_t, iters):
+            return ctx.intersect_device_timed(scene, env, rays_t.data_ptr(), out_t.data_ptr(), rays_t.shape[0], iters)
+        # one launch at a time (what round 1 reported as `value`): the launch's drain is exposed
+        timed_serial(d_rays, outs[1], 2)
+        t1 = time.perf_counter()
+        serial_ms = timed_serial(d_rays, outs[1], args.steps)
+        extras["one_launch_at_a_time"] = {"mrays_per_s": round(args.steps * n / (time.perf_counter() - t1) / 1e6, 1),
+                                          "kernel_ms_avg": round(float(np.mean(serial_ms)), 4)}
+        if not torch.equal(outs[1].view(torch.int32), d_out.view(torch.int32)):   # bit compare (a miss id reads as NaN in f32)
+            sys.exit("bench: overlapped launches changed the results")
         d_prim = torch.from_numpy(primary.view(np.float32).reshape(len(primary), 8).copy()).cuda()
         d_prim_out = torch.zeros((len(primary), 4), dtype=torch.float32, device="cuda")
-        run(2, d_prim, d_prim_out)
-        pm = float(np.median(run(10, d_prim, d_prim_out)))
+        timed_serial(d_prim, d_prim_out, 2)
+        pm = float(np.median(timed_serial(d_prim, d_prim_out, 10)))
         extras["coherent_1M"] = {"ms_per_step": round(pm, 4), "mrays_per_s": round(len(primary) / pm / 1e3, 1)}
-        # The reference keeps gpuSubmissionThreads (4) streams in flight (RayAccelerator.cpp:436,711-717).  Same K steps
-        # issued round-robin over 4 lanes (HIP streams): launches overlap, so one launch's drain hides under the next
-        # one's bulk.  Reported beside `value`, which stays the one-launch-at-a-time figure the roofline is quoted on.
-        outs = [torch.zeros((n, 4), dtype=torch.float32, device="cuda") for _ in range(4)]
-        for lane in range(4):
-            ctx.intersect_device(scene, env, d_rays.data_ptr(), outs[lane].data_ptr(), n, lane=lane)
-        for lane in range(4):
-            ctx.wait(lane)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for k in range(args.steps):
-            ctx.intersect_device(scene, env, d_rays.data_ptr(), outs[k % 4].data_ptr(), n, lane=k % 4)
-        for lane in range(4):
-            ctx.wait(lane)
-        torch.cuda.synchronize()
-        extras["four_streams_in_flight_mrays_per_s"] = round(args.steps * n / (time.perf_counter() - t1) / 1e6, 1)
-        if not torch.equal(outs[0].view(torch.int32), d_out.view(torch.int32)):   # bit compare (a miss id reads as NaN in f32)
-            sys.exit("bench: overlapped launches changed the results")
         # PCIe-inclusive rate of the host-buffer entry point (never `value`)
         res_host = np.zeros(n, ra.RESULT_DTYPE)
         ctx.intersect(scene, env, bounce, res_host)
@@ -191,14 +241,16 @@ def main():
             t1 = time.perf_counter()
             for _ in range(5):
                 ctx.intersect(scene, env, ray_host, res_host)
-            extras["host_buffers_page_locked_mrays_per_s"] = round(5 * n / (time.perf_counter() - t1) / 1e6, 1)
+            dt = (time.perf_counter() - t1) / 5
+            extras["host_buffers_page_locked_mrays_per_s"] = round(n / dt / 1e6, 1)
+            extras["host_buffers_page_locked_pcie_gbs"] = round(n * 48 / dt / 1e9, 1)      # 32 B in + 16 B out per ray; link: ~63 GB/s per direction
             if not np.array_equal(res_host["triangle"], d_out.cpu().numpy().view(ra.RESULT_DTYPE).reshape(-1)["triangle"]):
                 sys.exit("bench: the sliced host-buffer path changed the results")
             lib.racc_hip_unregister_host(ctx._h, ray_host.ctypes.data)
             lib.racc_hip_unregister_host(ctx._h, res_host.ctypes.data)
 
         # Batch-size scaling of the traversal kernel (same diffuse rays, 8 sample sets): T(N) = fixed + per-ray cost.
-        if world == 1 and full:
+        if world == 1 and full and args.mode == "weak":
             many = np.concatenate([bounce] + [synth.diffuse_bounce_rays(sc, primary, primary_hits, RAYS_PER_BATCH, first_sample=k) for k in range(1, 8)])
             d_many = torch.from_numpy(many.view(np.float32).reshape(len(many), 8).copy()).cuda()
             d_many_out = torch.zeros((len(many), 4), dtype=torch.float32, device="cuda")
@@ -214,7 +266,7 @@ def main():
         # BASELINE configs[4]: the path tracer, 1920x1080, end to end on this GPU.  Device-resident consumer (generation and
         # shading kernels around racc_hip_intersect_device) at 64 spp; the reference-shaped consumer (spawn/shade callbacks on
         # host threads through racc::render, PCIe both ways) at 8 spp.  Both render the same image (tests/test_gpu_pathtracer.py).
-        if world == 1 and full:
+        if world == 1 and full and args.mode == "weak":
             import tempfile
             from rayaccel_amd.engine import path_trace
             tmp = tempfile.NamedTemporaryFile(suffix=".bin", delete=False)
@@ -233,9 +285,9 @@ def main():
     # ---- roofline + CPU baseline (rank 0) --------------------------------------------------------
     roofline, cpu_baseline = None, None
     if rank == 0:
-        avg_kernel_ms = float(np.mean(kernel_ms))
+        avg_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else None
         alg_bytes, src = None, None
-        if not args.no_cpu_baseline and world == 1:       # the CPU legs run at N=1 only
+        if not args.no_cpu_baseline and world == 1 and args.mode == "weak":       # the CPU legs run at N=1 only
             from oracle import oracle            # checker / CPU leg only; never on the product path
             blobs = host.blobs()
             ref, nv, npairs, _ = oracle.traverse(blobs, bounce, env=sc["env"], counters=True)
@@ -258,7 +310,15 @@ def main():
             cpu_baseline = {"value": round(n / float(np.median(times)) / 1e6, 2), "unit": "Mrays/s", "cores": threads,
                             "kind": "port",
                             "sample": "the full 1,048,576-ray diffuse batch, %d passes per timing x 3 timings (median), %d pthreads x "
-                                      "1024-ray slices; CPU BVH2 restatement standing in for Embree (Embree unavailable)" % (repeat, threads)}
+                                      "1024-ray slices; SCALAR BVH2 port of the reference's traversal, not Embree-class "
+                                      "(the reference's CPU path is binary-only Embree 2.x bvh8/AVX2, unavailable here; "
+                                      "oracle/embree_adapter.py adds a row when a system Embree exists)" % (repeat, threads)}
+            try:        # optional second CPU row: a system Embree through oracle/embree_adapter.py, if one is installed
+                from oracle import embree_adapter
+                if embree_adapter.available():
+                    cpu_baseline["embree"] = embree_adapter.time_batch(sc, bounce, threads)
+            except Exception as e:   # noqa: BLE001
+                cpu_baseline["embree"] = {"error": str(e)[:200]}
             # The reference's OWN traversal kernel (oracle/_ref, built from RayAccelerator/Kernels.h with its own flags) on this
             # same GPU and batch, launched as the reference launches it (work-groups of 8, enqueue + clFinish).
             try:
@@ -276,30 +336,51 @@ def main():
         else:
             try:
                 with open(os.path.join(ROOT, "tests", "golden", "algorithmic_bytes.json")) as f:
-                    alg_bytes = json.load(f)["diffuse_1M_sample0"]["bytes"] if full else None
+                    alg_bytes = json.load(f)["diffuse_1M_sample0"]["bytes"] if (full and args.mode == "weak") else None
                     src = "tests/golden/algorithmic_bytes.json"
             except (OSError, KeyError, ValueError):
                 pass
-        if alg_bytes:
-            achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
-            traffic = _committed_traffic()
-            roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
+        if avg_kernel_ms:
+            # `bound: hbm` is BASELINE's yard-stick.  The PHYSICAL HBM traffic of a launch (rocprofv3 FETCH_SIZE/WRITE_SIZE,
+            # corrected as the guide prescribes) over the kernel's duration is `achieved`: the 55 MB scene lives in L2 and the
+            # Infinity Cache, so this is a few per cent of the 8 TB/s — the kernel is nowhere near an HBM bound and the
+            # fraction says so.  The algorithmic bytes of SURVEY §8(d) (every node / pair the reference's traversal order
+            # touches) are reported beside it: they exceed what HBM could deliver, because caches serve them.  What does bind
+            # the kernel is in `limiter` (from the same committed profile).
+            prof = committed_profile()
+            traffic = prof.get("hbm_bytes_per_launch") if (prof and full and args.mode == "weak") else None      # measured on THIS workload only
+            kernels_in_flight = max(1.0, avg_kernel_ms * args.steps / (elapsed * 1e3)) if world == 1 else None
+            roofline = {"bound": "hbm", "achieved": round(traffic / (avg_kernel_ms * 1e-3) / 1e9, 1) if traffic else None,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                        "traffic": traffic,
                         "kernel": KERNEL_NAME, "kernel_ms_avg": round(avg_kernel_ms, 4),
-                        "algorithmic_bytes_per_launch": int(alg_bytes), "algorithmic_bytes_source": src,
-                        "frac_of_measured_6290": round(achieved / HBM_MEASURED_GBS, 4)}
+                        "kernel_ms_avg_note": "HIP events around every traversal kernel of the timed region on its own stream; launches of different lanes overlap, "
+                                              "so a kernel shares the GPU with its neighbours (avg %.2f in flight) and lasts longer than alone "
+                                              "(see one_launch_at_a_time.kernel_ms_avg)" % (kernels_in_flight or 0.0),
+                        "algorithmic": None if not alg_bytes else {
+                            "bytes_per_launch": int(alg_bytes), "source": src,
+                            "gbs": round(alg_bytes / (avg_kernel_ms * 1e-3) / 1e9, 1),
+                            "x_hbm_peak": round(alg_bytes / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "note": "served by L2 / Infinity Cache, not HBM: not a fraction of any physical ceiling"},
+                        "limiter": None if not prof else {k: prof.get(k) for k in (
+                            "bound", "td_busy_frac", "ta_busy_frac", "valu_busy_frac", "issue_slot_frac", "valu_lane_util", "salu_share",
+                            "l2_hit_rate", "hbm_physical_frac_isolated", "kernel_ms_isolated", "source")},
+                        "profile_stale": bool(prof["stale"]) if prof else None}
+            if prof and prof["stale"]:
+                print("bench: %s was taken with other kernel sources; re-run tools/profile_bench.sh + tools/summarize_profile.py" % PROFILE_DIR, file=sys.stderr)
 
         line = {
             "metric": "Mrays/s", "value": round(value, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.mode, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "battlefield-synth (stand-in; reference scene unavailable), %d triangles, "
-                                   "1M 1st-bounce diffuse rays per GPU (BASELINE configs[2]/[3])" % len(sc["indices"]),
+            "config": {"workload": ("battlefield-synth (stand-in; reference scene unavailable), %d triangles, " % len(sc["indices"])) +
+                                   ("1M 1st-bounce diffuse rays per GPU per step (BASELINE configs[2]/[3]), steps issued back to back over %d engine lanes" % lanes
+                                    if args.mode == "weak" else "ONE 8M-ray 1st-bounce diffuse batch per step cut into %d contiguous shards (BASELINE configs[3])" % world),
                        "rays_per_gpu": n, "scene": sc["name"], "parallelism": "rays sharded x%d, scene replicated" % world,
-                       "grid_blocks": launch["grid_blocks"], "waves_per_simd": launch["waves_per_simd"]},
+                       "grid_blocks": launch["grid_blocks"], "waves_per_simd": launch["waves_per_simd"], "lanes": lanes},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         line.update(extras)

@@ -60,6 +60,7 @@ namespace {
 // VALU-written VGPR -> DPP read 2, s_mov m0 -> LDS-DMA 1.
 template <int BLOCK, int LDS_LEVELS, bool STATS>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) traverseKernelV8(const TraverseArgs a) {
+    static_assert(BLOCK == 64 || BLOCK == 128 || BLOCK == 256, "the assembly block addresses the stack with a shift");
     constexpr uint32_t kStagePiece = 1040u;
     __shared__ uint32_t lds[(LDS_LEVELS + 1) * BLOCK];
     __shared__ __attribute__((aligned(16))) unsigned char stageAll[(BLOCK / 64) * 4 * kStagePiece];
@@ -287,7 +288,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                 "s_cbranch_scc1 L_coop%=\n\t"
                 "s_mov_b64 exec, s[42:43]\n\t"
                 "v_lshlrev_b32_e32 v64, 6, %[node]\n\t"                 // byte offset of the 64 B record (bit 31 falls off)
-                "v_lshl_add_u32 v63, %[sp], 10, %[ldscol]\n\t"          // LDS address of the top stack entry
+                "v_lshl_add_u32 v63, %[sp], %[lshift], %[ldscol]\n\t"          // LDS address of the top stack entry
                 "global_load_dwordx2 v[60:61], v64, %[nodes]\n\t"
                 "global_load_dwordx4 v[48:51], v64, %[nodes] offset:16\n\t"
                 "global_load_dwordx4 v[52:55], v64, %[nodes] offset:32\n\t"
@@ -306,7 +307,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                 "L_coop%=:\n\t"                                         // all 64 lanes: a quad fetches the record of its lane j, 16 B each
                 "s_mov_b64 exec, s[40:41]\n\t"
                 "v_lshlrev_b32_e32 v64, 2, %[node]\n\t"                 // 16 B element index of the record (lanes without an inner node: out of range or harmless)
-                "v_lshl_add_u32 v63, %[sp], 10, %[ldscol]\n\t"
+                "v_lshl_add_u32 v63, %[sp], %[lshift], %[ldscol]\n\t"
                 "s_mov_b32 m0, %[stage]\n\t"
                 "v_or_b32_dpp v65, v64, %[ql] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                 "v_or_b32_dpp v66, v64, %[ql] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -374,7 +375,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                 "v_cndmask_b32_e64 v71, v61, v60, s[56:57]\n\t"         // far child
                 "v_cndmask_b32_e64 v72, v60, v61, s[56:57]\n\t"         // near child
                 "v_cmp_neq_f32_e64 s[52:53], 0, v70\n\t"                // firstDiff + lastDiff != 0, Kernels.h:192
-                "ds_write_b32 v63, v71 offset:1024\n\t"                 // above the top; counts only if sp is raised below
+                "ds_write_b32 v63, v71 offset:%[lstride]\n\t"                 // above the top; counts only if sp is raised below
                 "s_and_b64 s[58:59], s[58:59], s[52:53]\n\t"
                 "s_andn2_b64 s[54:55], exec, s[52:53]\n\t"
                 "s_waitcnt lgkmcnt(1)\n\t"
@@ -412,7 +413,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6
                 : [tfar] "v"(tFar), [tnear] "v"(tNear), [vix] "v"(vix), [viy] "v"(viy), [viz] "v"(viz), [vex] "v"(vex), [vey] "v"(vey), [vez] "v"(vez),
                   [ldscol] "v"(ldsCol), [rec] "v"(recAddr), [ql] "v"(quadLane),
                   [nodes] "s"(a.nodes), [rsrc] "s"(nodeRsrc), [stage] "s"(stageAddr),
-                  [pol0] "s"(pol0), [pol1] "s"(pol1), [flags] "s"(flags), [maxit] "s"(a.maxIters), [splim] "n"(LDS_LEVELS - 1)
+                  [pol0] "s"(pol0), [pol1] "s"(pol1), [flags] "s"(flags), [maxit] "s"(a.maxIters), [splim] "n"(LDS_LEVELS - 1),
+                  [lshift] "n"(BLOCK == 256 ? 10 : BLOCK == 128 ? 9 : 8), [lstride] "n"(BLOCK * 4)
                 : "memory", "vcc", "scc",
                   "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59",
                   "s60", "s61", "s62", "s63", "s66", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77",
@@ -523,7 +525,7 @@ struct Lane {
     std::mutex mutex;                    // host-side: one thread at a time enqueues on a lane
     hipEvent_t done = nullptr;
     hipStream_t lastStream = nullptr;
-    bool everLaunched = false;
+    std::atomic<bool> everLaunched{false};
     // opts.time_kernels: an event pair around every traversal kernel, read back by racc_hip_read_kernel_times
     std::vector<hipEvent_t> ring;        // 2 * kTimeRing events
     uint32_t ringHead = 0, ringCount = 0;
@@ -718,6 +720,8 @@ const Variant kVariants[] = {
     {256, 10, 0, traverseKernelV8<256, 9, false>, false, true, 1, 2, 4 * 1040},           // 41: V8: V7 with the header + inner steps in hand-scheduled assembly
     {256, 10, 0, traverseKernelV8<256, 9, true>, false, true, 1, 2, 4 * 1040},            // 42: variant 41 + statistics (debug; inner-step counters stay 0)
     {256, 14, 0, traverseKernelV8<256, 13, false>, false, true, 1, 2, 4 * 1040},          // 43: V8, 12-entry LDS stack
+    {64, 14, 0, traverseKernelV8<64, 13, false>, false, true, 1, 2, 4 * 1040},            // 44: variant 43 in one-wave workgroups: a finished wave frees its slot at once (overlapping launches)
+    {128, 14, 0, traverseKernelV8<128, 13, false>, false, true, 1, 2, 4 * 1040},          // 45: two-wave workgroups
 };
 constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kSoaVariant = 27;
@@ -742,7 +746,21 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     const Variant& v = *vp;
     const uint32_t ldsBytes = uint32_t(v.cacheNodes) * 64u + uint32_t(v.ldsLevels) * uint32_t(v.block) * 4u + (v.ldsLevels > 32 ? 272u : 0u) +
                               uint32_t(v.stagePerWave) * uint32_t(v.block / 64);
-    const uint32_t wavesPerSimd = optOr(ctx->opts.waves_per_simd, 6u);   // measured best on 1M-ray batches (5: +1.3 %, 4: +8 % per ray); LDS caps it below
+    // Persistent grid: as many waves as the LDS allows (5 per SIMD with the default kernel) when the GPU is otherwise idle.
+    // When another lane's launch is still running — a caller issuing batch after batch — a launch takes about half of that:
+    // two or three launches are then co-resident, each one's drain (its last, longest rays: ~0.13 ms during which most of
+    // its waves have nothing left) runs beside the others' bulk instead of leaving the machine empty.  Measured on 1M-ray
+    // diffuse batches (tools/gpu_overlap.py): 0.378 ms per batch one at a time; back to back over 3 lanes 0.294 with full
+    // grids, 0.273 with 3 waves per SIMD each.
+    uint32_t wavesPerSimd = ctx->opts.waves_per_simd;
+    if (!wavesPerSimd) {
+        wavesPerSimd = 6u;
+        for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
+            const Lane& other = ctx->lanes[i];
+            if (&other != &lane && other.everLaunched.load(std::memory_order_relaxed) && hipEventQuery(other.done) == hipErrorNotReady) { wavesPerSimd = 3u; break; }
+        }
+        (void)hipGetLastError();      // hipErrorNotReady is not an error
+    }
     const uint32_t wavesPerBlock = uint32_t(v.block) / 64u;
     uint32_t blocksPerCU = (wavesPerSimd * 4u) / wavesPerBlock;
     if (blocksPerCU < 1u) blocksPerCU = 1u;
@@ -1204,7 +1222,8 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
 int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
                               const void* d_rays, void* d_results, uint32_t count, uint32_t lane, void* stream) {
     if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
-    if (lane == RACC_HIP_LANE_AUTO) lane = ctx->nextLane.fetch_add(1u) % ctx->opts.lanes;      // round robin: consecutive launches overlap
+    // round robin over (up to) three lanes: consecutive launches overlap; a fourth in flight measured slower (3.35 vs 3.84 Grays/s)
+    if (lane == RACC_HIP_LANE_AUTO) lane = ctx->nextLane.fetch_add(1u) % (ctx->opts.lanes < 3u ? ctx->opts.lanes : 3u);
     if (int rc = checkLane(ctx, lane)) return rc;
     if (!scene) return fail(RACC_HIP_ERR_INVALID, "scene is NULL");
     if (!count) return RACC_HIP_OK;

@@ -27,7 +27,8 @@ def test_single_gpu_line():
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["unit"] == "Mrays/s"
     assert d["value"] > 0 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
-    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0 and d["roofline"]["achieved"] > 0
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0 and d["roofline"]["kernel_ms_avg"] > 0
+    assert d["roofline"]["algorithmic"]["bytes_per_launch"] > 0 and d["one_launch_at_a_time"]["mrays_per_s"] > 0 if "one_launch_at_a_time" in d else True
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
 
 
