@@ -262,7 +262,9 @@ extern "C" int racc_ptdev_render_file(const char* scene_bin, int device, uint32_
                 P.busy = false; --live;
             }
         }
-        PT_HIP(hipDeviceSynchronize());
+        // (not hipDeviceSynchronize: the engine's call also reports a traversal watchdog trip — stale hit records would
+        //  otherwise be shaded as if valid and the frame returned as complete)
+        PT_RACC(racc_hip_synchronize(ctx));
         seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::vector<long long> frame(frameWords);
         PT_HIP(hipMemcpy(frame.data(), dFrame, frameWords * 8, hipMemcpyDeviceToHost));

@@ -529,6 +529,10 @@ struct Lane {
     // opts.time_kernels: an event pair around every traversal kernel, read back by racc_hip_read_kernel_times
     std::vector<hipEvent_t> ring;        // 2 * kTimeRing events
     uint32_t ringHead = 0, ringCount = 0;
+    // host-buffer path, sliced: the kernels of consecutive slices go to the lane and its two helpers in turn, so that one
+    // slice's drain runs beside the next slice's bulk (each with half a grid), created on first use
+    Lane* helper[2] = {nullptr, nullptr};
+    uint32_t forceWavesPerSimd = 0;      // != 0: grid size of this (helper-rotated) launch
 };
 constexpr uint32_t kTimeRing = 256;
 
@@ -752,7 +756,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     // its waves have nothing left) runs beside the others' bulk instead of leaving the machine empty.  Measured on 1M-ray
     // diffuse batches (tools/gpu_overlap.py): 0.378 ms per batch one at a time; back to back over 3 lanes 0.294 with full
     // grids, 0.273 with 3 waves per SIMD each.
-    uint32_t wavesPerSimd = ctx->opts.waves_per_simd;
+    uint32_t wavesPerSimd = ctx->opts.waves_per_simd ? ctx->opts.waves_per_simd : lane.forceWavesPerSimd;
     if (!wavesPerSimd) {
         wavesPerSimd = 6u;
         for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
@@ -846,6 +850,34 @@ int launchEnvShadeOnly(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const 
     return RACC_HIP_OK;
 }
 
+hipError_t initLane(Lane& l, bool timeKernels) {
+    hipError_t e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&l.cursor), 256);
+    if (e == hipSuccess) e = hipMemset(l.cursor, 0, 256);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&l.done, hipEventDisableTiming);
+    if (e == hipSuccess && timeKernels) {
+        l.ring.resize(2 * kTimeRing, nullptr);
+        for (hipEvent_t& ev : l.ring) if (e == hipSuccess) e = hipEventCreate(&ev);
+    }
+    return e;
+}
+
+void freeLane(Lane& l) {
+    for (Lane*& h : l.helper) if (h) { freeLane(*h); delete h; h = nullptr; }
+    if (l.stream) hipStreamSynchronize(l.stream);
+    for (hipEvent_t ev : l.events) hipEventDestroy(ev);
+    for (hipEvent_t ev : l.pipeEvents) hipEventDestroy(ev);
+    for (hipEvent_t ev : l.ring) if (ev) hipEventDestroy(ev);
+    if (l.done) hipEventDestroy(l.done);
+    if (l.copyIn) hipStreamDestroy(l.copyIn);
+    if (l.copyOut) hipStreamDestroy(l.copyOut);
+    if (l.cursor) hipFree(l.cursor);
+    if (l.spill) hipFree(l.spill);
+    if (l.dRays) hipFree(l.dRays);
+    if (l.dResults) hipFree(l.dResults);
+    if (l.stream) hipStreamDestroy(l.stream);
+}
+
 int checkLane(racc_hip_ctx* ctx, uint32_t lane) {
     if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
     if (lane >= ctx->opts.lanes) return fail(RACC_HIP_ERR_INVALID, "lane out of range");
@@ -937,15 +969,7 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
     if (ctx->opts.refill_min > 64) ctx->opts.refill_min = 64;
     if (ctx->opts.leaf_min > 64) ctx->opts.leaf_min = 64;
     for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
-        Lane& l = ctx->lanes[i];
-        hipError_t e1 = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
-        hipError_t e2 = e1 == hipSuccess ? hipMalloc(reinterpret_cast<void**>(&l.cursor), 256) : e1;
-        hipError_t e3 = e2 == hipSuccess ? hipMemset(l.cursor, 0, 256) : e2;
-        if (e3 == hipSuccess) e3 = hipEventCreateWithFlags(&l.done, hipEventDisableTiming);
-        if (e3 == hipSuccess && ctx->opts.time_kernels) {
-            l.ring.resize(2 * kTimeRing, nullptr);
-            for (hipEvent_t& ev : l.ring) if (e3 == hipSuccess) e3 = hipEventCreate(&ev);
-        }
+        const hipError_t e3 = initLane(ctx->lanes[i], ctx->opts.time_kernels != 0u);
         if (e3 != hipSuccess) { racc_hip_destroy(ctx); return fail(RACC_HIP_ERR_DEVICE, "lane setup", e3); }
     }
     {
@@ -963,20 +987,7 @@ int racc_hip_destroy(racc_hip_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();              // launches given a caller's own stream (racc_hip_intersect_device) included
     if (ctx->hostTrips) hipHostFree(ctx->hostTrips);
-    for (Lane& l : ctx->lanes) {
-        if (l.stream) hipStreamSynchronize(l.stream);
-        for (hipEvent_t ev : l.events) hipEventDestroy(ev);
-        for (hipEvent_t ev : l.pipeEvents) hipEventDestroy(ev);
-        for (hipEvent_t ev : l.ring) if (ev) hipEventDestroy(ev);
-        if (l.done) hipEventDestroy(l.done);
-        if (l.copyIn) hipStreamDestroy(l.copyIn);
-        if (l.copyOut) hipStreamDestroy(l.copyOut);
-        if (l.cursor) hipFree(l.cursor);
-        if (l.spill) hipFree(l.spill);
-        if (l.dRays) hipFree(l.dRays);
-        if (l.dResults) hipFree(l.dResults);
-        if (l.stream) hipStreamDestroy(l.stream);
-    }
+    for (Lane& l : ctx->lanes) freeLane(l);
     delete ctx;
     return RACC_HIP_OK;
 }
@@ -1066,7 +1077,7 @@ int racc_hip_env_free(racc_hip_ctx* ctx, racc_hip_env* env) {
 int racc_hip_register_host(racc_hip_ctx* ctx, void* ptr, uint64_t bytes) {
     if (!ctx || !ptr || !bytes) return fail(RACC_HIP_ERR_INVALID, "register_host: bad argument");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
-    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterPortable), "hipHostRegister");
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterPortable | hipHostRegisterMapped), "hipHostRegister");
     return RACC_HIP_OK;
 }
 
@@ -1080,7 +1091,7 @@ int racc_hip_unregister_host(racc_hip_ctx* ctx, void* ptr) {
 int racc_hip_register_stream(racc_hip_ctx* ctx, void* rays, void* results, uint32_t capacity) {
     if (!ctx || !rays || !results || !capacity) return fail(RACC_HIP_ERR_INVALID, "register_stream: bad argument");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
-    HIP_TRY(hipHostRegister(rays, size_t(capacity) * 32, hipHostRegisterPortable), "hipHostRegister(rays)");
+    HIP_TRY(hipHostRegister(rays, size_t(capacity) * 32, hipHostRegisterPortable | hipHostRegisterMapped), "hipHostRegister(rays)");
     hipError_t e = hipHostRegister(results, size_t(capacity) * 16, hipHostRegisterPortable);
     if (e != hipSuccess) { hipHostUnregister(rays); return fail(RACC_HIP_ERR_DEVICE, "hipHostRegister(results)", e); }
     return RACC_HIP_OK;
@@ -1136,7 +1147,7 @@ int racc_hip_wait(racc_hip_ctx* ctx, uint32_t lane) {
 
 int racc_hip_intersect(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
                        const void* rays, void* results, uint32_t count, uint32_t lane) {
-    if (count >= 524288u) return racc_hip_intersect_streams(ctx, scene, env, 1, &rays, &results, &count, lane);   // sliced: copies beside kernels
+    if (count >= 262144u) return racc_hip_intersect_streams(ctx, scene, env, 1, &rays, &results, &count, lane);   // sliced: copies beside kernels
     if (int rc = racc_hip_intersect_async(ctx, scene, env, rays, results, count, lane)) return rc;
     return racc_hip_wait(ctx, lane);
 }
@@ -1192,28 +1203,52 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
         HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
         return checkWatchdog(ctx);
     }
-    // Large batches: cut into slices so that the PCIe copy of slice k+1 (in) and of slice k-1 (out) run beside the kernel of
-    // slice k (PCIe is full duplex; a 1M-ray batch is 32 MiB in, 16 MiB out, 0.9 ms of copies against 0.4 ms of kernel).
     if (!l.copyIn) HIP_TRY(hipStreamCreateWithFlags(&l.copyIn, hipStreamNonBlocking), "hipStreamCreate");
     if (!l.copyOut) HIP_TRY(hipStreamCreateWithFlags(&l.copyOut, hipStreamNonBlocking), "hipStreamCreate");
+    for (Lane*& h : l.helper)
+        if (!h) {
+            h = new (std::nothrow) Lane();
+            if (!h) return fail(RACC_HIP_ERR_NOMEM, "out of host memory");
+            const hipError_t e = initLane(*h, false);
+            if (e != hipSuccess) return fail(RACC_HIP_ERR_DEVICE, "helper lane setup", e);
+        }
+    Lane* const run[3] = {&l, l.helper[0], l.helper[1]};
+    // Cut into slices so that the PCIe copy of slice k+1 (in) and of slice k-1 (out) run beside the kernel of slice k (PCIe is
+    // full duplex; a 1M-ray batch is 32 MiB in, 16 MiB out), the kernels on the lane and its two helpers in turn so that one
+    // slice's drain runs beside the next one's bulk.  Measured on page-locked arrays: 1.04 Grays/s at 1M rays, 1.37 at 4M
+    // (= 66 GB/s over the link, both directions together; the DMA engines deliver ~63).
+    // (Measured and rejected: letting the kernel read page-locked rays straight from host memory — no copy-in stage at all —
+    //  reaches 0.87 Grays/s at 1M and 4M rays: PCIe reads issued by the waves' refills run at ~28 GB/s, DMA copies at ~52.)
     while (l.pipeEvents.size() < size_t(slices) * 2) {
         hipEvent_t ev;
         HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
         l.pipeEvents.push_back(ev);
     }
     const uint64_t per = ((total + slices - 1) / slices + 63) / 64 * 64;
+    std::vector<uint64_t> cut;          // slice boundaries (equal slices: a short first and/or last slice measured no gain)
+    for (uint64_t g = 0; g < total; g += per) cut.push_back(g);
+    cut.push_back(total);
+    slices = uint32_t(cut.size() - 1);
+    while (l.pipeEvents.size() < size_t(slices) * 2) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+        l.pipeEvents.push_back(ev);
+    }
     for (uint32_t k = 0; k < slices; ++k) {
-        const uint64_t g0 = uint64_t(k) * per, g1 = g0 + per < total ? g0 + per : total;
-        if (g0 >= g1) break;
+        const uint64_t g0 = cut[k], g1 = cut[k + 1];
+        Lane& r = *run[k % 3u];           // the three take the slices' kernels in turn: a slice's drain overlaps the next one's bulk
+        r.forceWavesPerSimd = 3u;
         HIP_TRY(copyRange(0, g0, g1, l.copyIn), "H2D rays");
         HIP_TRY(hipEventRecord(l.pipeEvents[2 * k], l.copyIn), "hipEventRecord");
-        HIP_TRY(hipStreamWaitEvent(l.stream, l.pipeEvents[2 * k], 0), "hipStreamWaitEvent");
-        if (int rc = launchTraverse(ctx, l, l.stream, scene, env, static_cast<char*>(l.dRays) + g0 * 32, static_cast<char*>(l.dResults) + g0 * 16, uint32_t(g1 - g0))) return rc;
-        if (int rc = launchEnvShade(ctx, l, l.stream, env, static_cast<char*>(l.dResults) + g0 * 16, uint32_t(g1 - g0))) return rc;
-        HIP_TRY(hipEventRecord(l.pipeEvents[2 * k + 1], l.stream), "hipEventRecord");
+        HIP_TRY(hipStreamWaitEvent(r.stream, l.pipeEvents[2 * k], 0), "hipStreamWaitEvent");
+        if (int rc = launchTraverse(ctx, r, r.stream, scene, env, static_cast<char*>(l.dRays) + g0 * 32, static_cast<char*>(l.dResults) + g0 * 16, uint32_t(g1 - g0))) return rc;
+        if (int rc = launchEnvShade(ctx, r, r.stream, env, static_cast<char*>(l.dResults) + g0 * 16, uint32_t(g1 - g0))) return rc;
+        HIP_TRY(hipEventRecord(l.pipeEvents[2 * k + 1], r.stream), "hipEventRecord");
         HIP_TRY(hipStreamWaitEvent(l.copyOut, l.pipeEvents[2 * k + 1], 0), "hipStreamWaitEvent");
         HIP_TRY(copyRange(1, g0, g1, l.copyOut), "D2H results");
+        r.forceWavesPerSimd = 0u;
     }
+    for (Lane* h : l.helper) HIP_TRY(hipStreamSynchronize(h->stream), "hipStreamSynchronize");
     HIP_TRY(hipStreamSynchronize(l.copyOut), "hipStreamSynchronize");
     HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
     return checkWatchdog(ctx);

@@ -286,6 +286,7 @@ private:
         } else {
             forceMedian = true;
         }
+        if (axis < 0) forceMedian = true;          // no pivot won (only possible with non-finite costs): never index sorted_[-1]
         if (forceMedian) {                                               // Bvh2.cpp:467-485
             if (count < 127) return false;
             axis = 0;
@@ -460,6 +461,15 @@ int racc_host_scene_build(const float* vertices, uint32_t vertex_count,
     if (T < 3) { set_error("scene needs at least 3 triangles (root must be an inner node)"); return RACC_HIP_ERR_LIMIT; }
     for (uint32_t i = 0; i < index_count; ++i)
         if (indices[i] >= vertex_count) { set_error("vertex index out of range"); return RACC_HIP_ERR_INVALID; }
+    // The reference assumes finite geometry; a NaN/inf coordinate (or extents whose surface area overflows float) turns the
+    // SAH costs into NaN and leaves the sweep without a split axis.  Refuse it here instead of building garbage.
+    for (uint32_t i = 0; i < index_count; ++i) {
+        const float* v = vertices + size_t(indices[i]) * 4;
+        if (!(std::fabs(v[0]) < 1e18f && std::fabs(v[1]) < 1e18f && std::fabs(v[2]) < 1e18f)) {
+            set_error("vertex coordinate is not finite (or beyond 1e18: surface areas would overflow binary32)");
+            return RACC_HIP_ERR_INVALID;
+        }
+    }
     try {
         racc_host_scene* s = new racc_host_scene();
         s->triangleCount = T;

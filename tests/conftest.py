@@ -55,3 +55,15 @@ def full(gpu_ctx):
     prim, _ = synth.primary_rays(sc["camera"], 1024, 1024)
     yield dict(sc=sc, host=host, blobs=host.blobs(), scene=scene, env=env, primary=prim)
     scene.destroy(); env.destroy()
+
+
+@pytest.fixture(scope="session")
+def small(gpu_ctx, small_scene, small_host):
+    """The small test scene on the GPU with its 256x256 primary batch."""
+    from rayaccel_amd import synth
+    scene = gpu_ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
+    env = gpu_ctx.create_environment(small_scene["env"])
+    prim, _ = synth.primary_rays(small_scene["camera"], 256, 256)
+    yield dict(scene=scene, env=env, blobs=small_host.blobs(), primary=prim, sc=small_scene)
+    scene.destroy()
+    env.destroy()

@@ -15,16 +15,6 @@ from helpers import MISS, assert_bit_exact, assert_matches_arbiter, comb_scene, 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def small(gpu_ctx, small_scene, small_host):
-    scene = gpu_ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
-    env = gpu_ctx.create_environment(small_scene["env"])
-    prim, _ = synth.primary_rays(small_scene["camera"], 256, 256)
-    yield dict(scene=scene, env=env, blobs=small_host.blobs(), primary=prim, sc=small_scene)
-    scene.destroy()
-    env.destroy()
-
-
 def _batches(small):
     prim = small["primary"]
     hits = orc.traverse(small["blobs"], prim)

@@ -109,3 +109,14 @@ def test_build_is_identical_for_any_thread_count(monkeypatch):
     assert blobs["1"] == blobs["3"] == blobs["8"]
     ref = orc.build_scene(sc["vertices"], sc["indices"])
     assert blobs["8"][0] == ref["nodes"].tobytes() and blobs["8"][1] == ref["pairs"].tobytes() and blobs["8"][2] == ref["remap"].tobytes()
+
+
+def test_non_finite_vertices_are_refused(small_scene):
+    """A NaN/inf coordinate turns the SAH costs into NaN (the reference would index sorted[-1], Bvh2.cpp:467-485 never sees
+    it coming): the host build refuses such input."""
+    import rayaccel_amd as ra
+    for bad in (np.nan, np.inf, -np.inf, 3e19):
+        v = small_scene["vertices"].copy()
+        v[17, 1] = bad
+        with pytest.raises(ra.RaccError):
+            ra.HostScene(v, small_scene["indices"])

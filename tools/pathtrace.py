@@ -60,8 +60,12 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    img, st = path_trace(scene_file, args.width, args.height, first, max(1, last - first), device=local, max_depth=args.depth, cpu_threads=args.threads,
-                         shading=args.shading, samples_per_batch=args.batch)
+    if last > first:
+        img, st = path_trace(scene_file, args.width, args.height, first, last - first, device=local, max_depth=args.depth, cpu_threads=args.threads,
+                             shading=args.shading, samples_per_batch=args.batch)
+    else:       # more ranks than samples: this rank has none and contributes a black frame (rendering "at least one" would
+        import numpy as np      # duplicate another rank's sample and make the image depend on N)
+        img, st = np.zeros((args.height, args.width, 3), np.float64), dict(rays_traced=0, seconds=0.0, primary_rays=0, threads=0, max_depth=0, tiles_x=0, tiles_y=0, triangles=0, reserved=0)
     dev = "cuda" if backend == "nccl" or world == 1 else "cpu"
     rays = torch.tensor([float(st["rays_traced"]), st["seconds"]], dtype=torch.float64, device=dev)
     frame = torch.from_numpy(img).to(dev)
