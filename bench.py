@@ -350,18 +350,22 @@ def main():
             prof = committed_profile()
             traffic = prof.get("hbm_bytes_per_launch") if (prof and full and args.mode == "weak") else None      # measured on THIS workload only
             kernels_in_flight = max(1.0, avg_kernel_ms * args.steps / (elapsed * 1e3)) if world == 1 else None
-            roofline = {"bound": "hbm", "achieved": round(traffic / (avg_kernel_ms * 1e-3) / 1e9, 1) if traffic else None,
+            # launches overlap, so the GPU's HBM rate is bytes per launch over the time the region spends per launch
+            # (ms_per_step), not over one kernel's own (stretched) duration
+            step_s = elapsed / args.steps
+            roofline = {"bound": "hbm", "achieved": round(traffic / step_s / 1e9, 1) if traffic else None,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                        "frac": round(traffic / step_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                         "traffic": traffic,
+                        "achieved_note": "physical HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, %s) / ms_per_step of the timed region" % PROFILE_DIR,
                         "kernel": KERNEL_NAME, "kernel_ms_avg": round(avg_kernel_ms, 4),
                         "kernel_ms_avg_note": "HIP events around every traversal kernel of the timed region on its own stream; launches of different lanes overlap, "
                                               "so a kernel shares the GPU with its neighbours (avg %.2f in flight) and lasts longer than alone "
                                               "(see one_launch_at_a_time.kernel_ms_avg)" % (kernels_in_flight or 0.0),
                         "algorithmic": None if not alg_bytes else {
                             "bytes_per_launch": int(alg_bytes), "source": src,
-                            "gbs": round(alg_bytes / (avg_kernel_ms * 1e-3) / 1e9, 1),
-                            "x_hbm_peak": round(alg_bytes / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "gbs": round(alg_bytes / step_s / 1e9, 1),
+                            "x_hbm_peak": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
                             "note": "served by L2 / Infinity Cache, not HBM: not a fraction of any physical ceiling"},
                         "limiter": None if not prof else {k: prof.get(k) for k in (
                             "bound", "td_busy_frac", "ta_busy_frac", "valu_busy_frac", "issue_slot_frac", "valu_lane_util", "salu_share",

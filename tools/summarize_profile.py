@@ -43,7 +43,7 @@ for sub, name in (("stats", "kernel_stats.csv"), ("stats_one_lane", "kernel_stat
         shutil.copy(s, os.path.join(dst, name))
 _, out["kernel_trace"] = trace_durations("stats")
 _, out["kernel_trace_one_lane"] = trace_durations("stats_one_lane")
-for d in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
+for d in sorted(filter(None, (newest(os.path.join(p, "*", "*_counter_collection.csv")) for p in glob.glob(os.path.join(src, "pmc_*"))))):   # newest run of every pass
     byc = collections.defaultdict(list)
     for r in csv.DictReader(open(d)):
         if "traverseKernel" in r["Kernel_Name"]:
