@@ -59,7 +59,7 @@ namespace {
 // bit-identical.  Software wait states follow LLVM's GCNHazardRecognizer for gfx940+: VALU-written SGPR/VCC -> VALU read 2,
 // VALU-written VGPR -> DPP read 2, s_mov m0 -> LDS-DMA 1.
 template <int BLOCK, int LDS_LEVELS, bool STATS>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) traverseKernelV8(const TraverseArgs a) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_LEVELS > 9 ? 5 : 6, 6))) traverseKernelV8(const TraverseArgs a) {
     static_assert(BLOCK == 64 || BLOCK == 128 || BLOCK == 256, "the assembly block addresses the stack with a shift");
     constexpr uint32_t kStagePiece = 1040u;
     __shared__ uint32_t lds[(LDS_LEVELS + 1) * BLOCK];
