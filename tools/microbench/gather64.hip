@@ -60,6 +60,20 @@ __global__ void __launch_bounds__(256) gather(const float4* __restrict__ recs, u
             __builtin_amdgcn_s_waitcnt(0x0F70);
             const float4* mine = reinterpret_cast<const float4*>(base + lane * 16u);
             a = mine[0]; b = mine[64]; c = mine[128]; d = mine[192];
+        } else if (MODE == 8 || MODE == 9) {
+            // cooperative LDS-DMA with only ACTIVE of the 64 rays live.  8: scattered lanes, four loads, dead rays fetch an
+            // out-of-range element; 9: the live rays compacted to the first lanes, ceil(ACTIVE / 16) loads
+            unsigned char* base = stage[wave];
+            const bool act = MODE == 9 ? lane < unsigned(ACTIVE) : ((lane * 2654435761u) >> 26) < unsigned(ACTIVE);
+            const unsigned idxOrOut = act ? cur : 0x7FFFFFFFu;
+#define STEP(j) if (MODE == 8 || j * 16 < ACTIVE) __builtin_amdgcn_struct_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(base + j * 1040), 16, quadBroadcast<j>(idxOrOut), k * 16u, 0, 0, 0);
+            STEP(0) STEP(1) STEP(2) STEP(3)
+#undef STEP
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            if (act) {
+                const float4* mine = reinterpret_cast<const float4*>(base + myStage);
+                a = mine[0]; b = mine[1]; c = mine[2]; d = mine[3];
+            }
         } else {
             unsigned char* base = stage[wave];
 #define STEP(j) __builtin_amdgcn_struct_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(base + j * 1040), 16, quadBroadcast<j>(cur), k * 16u, 0, 0, 0);
@@ -87,7 +101,7 @@ int main() {
     hipMemcpy(recs, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(idx, hi.data(), nrec * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 8; ++mode) {
+    for (int mode = 0; mode < 14; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             if (mode == 0) gather<0><<<blocks, 256>>>(recs, nrec, idx, iters, out);
@@ -98,6 +112,12 @@ int main() {
             if (mode == 5) gather<5><<<blocks, 256>>>(recs, nrec, idx, iters, out);
             if (mode == 6) gather<0, 32><<<blocks, 256>>>(recs, nrec, idx, iters, out);     // mode 0 with ~half the lanes active
             if (mode == 7) gather<0, 16><<<blocks, 256>>>(recs, nrec, idx, iters, out);     // ~a quarter
+            if (mode == 8) gather<8, 40><<<blocks, 256>>>(recs, nrec, idx, iters, out);     // cooperative LDS-DMA, ~40 scattered live rays, 4 loads
+            if (mode == 9) gather<9, 40><<<blocks, 256>>>(recs, nrec, idx, iters, out);     // the same 40 rays compacted: 3 loads
+            if (mode == 10) gather<0, 40><<<blocks, 256>>>(recs, nrec, idx, iters, out);    // per lane, ~40 live
+            if (mode == 11) gather<8, 24><<<blocks, 256>>>(recs, nrec, idx, iters, out);
+            if (mode == 12) gather<9, 24><<<blocks, 256>>>(recs, nrec, idx, iters, out);    // 2 loads
+            if (mode == 13) gather<0, 24><<<blocks, 256>>>(recs, nrec, idx, iters, out);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             const double gathers = double(blocks) * 256 * iters;
