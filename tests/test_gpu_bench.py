@@ -38,3 +38,14 @@ def test_two_ranks_rehearsal():
                "--master-port", "29543", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--grid", "128", "--no-extras"], env)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["cpu_baseline"] is None      # the CPU legs run at N=1 only
     assert d["config"]["parallelism"].startswith("rays sharded x2")
+
+
+def test_strong_scaling_mode_two_ranks_rehearsal():
+    """BASELINE configs[3] as written: ONE 8M-ray batch per step cut into N contiguous shards (bench.py --mode strong),
+    rehearsed with two gloo ranks on GPU 0 (the RCCL gather step needs one GPU per rank and is skipped here; it runs on
+    hardware with a world of one rank in test_config3_8M_rays_in_8_shards)."""
+    env = dict(os.environ, RACC_BENCH_BACKEND="gloo", RACC_BENCH_DEVICE="0")
+    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29547", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--grid", "128", "--no-extras", "--mode", "strong"], env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["rays_per_gpu"] == 4 << 20 and "contiguous shards" in d["config"]["workload"]
