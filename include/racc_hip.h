@@ -62,7 +62,10 @@ typedef struct racc_hip_options {
                                   hipEventRecord per launch, so off by default */
     uint32_t drain_prefetch;   /* 1: thin waves of an exhausted batch touch both children's records as soon as a node's child refs
                                   arrive (measured: -3 % on a 64k-ray batch, +4..10 % on 256k..1M rays); 0 => default (off) */
-    uint32_t reserved[2];
+    uint32_t leaf_step;        /* 0/1 => the leaf step runs inside the kernel's assembly block and takes the inner lanes' step along
+                                  (one memory round trip for both); 2 => in C++ through the block's LEAF door; 3 => in the block,
+                                  not fused (A/B; same results) */
+    uint32_t reserved[1];
 } racc_hip_options;
 
 typedef struct racc_hip_scene_info {

@@ -59,8 +59,8 @@ namespace {
 // bit-identical.  Software wait states follow LLVM's GCNHazardRecognizer for gfx940+: VALU-written SGPR/VCC -> VALU read 2,
 // VALU-written VGPR -> DPP read 2, s_mov m0 -> LDS-DMA 1.
 template <int BLOCK, int LDS_LEVELS, bool STATS>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_LEVELS > 9 ? 5 : 6, 6))) traverseKernelV8(const TraverseArgs a) {
-    static_assert(BLOCK == 64 || BLOCK == 128 || BLOCK == 256, "the assembly block addresses the stack with a shift");
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) traverseKernelV8(const TraverseArgs a) {
+    static_assert(BLOCK == 256, "the assembly block addresses the stack with literal strides (level = 1 KiB)");
     constexpr uint32_t kStagePiece = 1040u;
     __shared__ uint32_t lds[(LDS_LEVELS + 1) * BLOCK];
     __shared__ __attribute__((aligned(16))) unsigned char stageAll[(BLOCK / 64) * 4 * kStagePiece];
@@ -72,7 +72,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_
     unsigned char* const stage = stageAll + wave * 4u * kStagePiece;
     typedef __attribute__((address_space(3))) unsigned char* lbyte_t;
     const uint32_t ldsCol = uint32_t(reinterpret_cast<uintptr_t>((lbyte_t)(reinterpret_cast<unsigned char*>(myLds))));            // LDS byte address of level 0
-    const uint32_t recAddr = uint32_t(reinterpret_cast<uintptr_t>((lbyte_t)(stage + (lane & 3u) * kStagePiece + (lane >> 2) * 64u)));
     const uint32_t stageAddr = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(reinterpret_cast<uintptr_t>((lbyte_t)stage)))));
     const __amdgpu_buffer_rsrc_t nodeRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.nodes), 16, a.nodeCount * 4u, 0x00020000);
     myLds[0] = kDone;           // the sentinel below every ray's stack (own column: no barrier needed)
@@ -90,10 +89,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_
     uint32_t stInner = 0, stInnerLanes = 0, stLeaf = 0, stLeafLanes = 0, stRefill = 0, stLoaded = 0, stDeq = 0;
     unsigned long long cyInner = 0, cyLeaf = 0, cyRefill = 0, cyStart = 0;
     if (STATS) cyStart = __builtin_readcyclecounter();
-    uint32_t quadLane = lane & 3u;
     // policy words for the assembly block: [refillMin | leafMin << 8 | tailActive << 16 | coopPct << 24], [thinReps | innerReps << 8]
     const uint32_t pol0 = uint32_t(__builtin_amdgcn_readfirstlane(int(min(a.refillMin, 255u) | (min(a.leafMin, 255u) << 8) | (min(a.tailActive, 255u) << 16) | (min(a.coopNum, 255u) << 24))));
-    const uint32_t pol1 = uint32_t(__builtin_amdgcn_readfirstlane(int(min(max(a.thinReps, 1u), 255u) | (min(max(a.innerReps, 1u), 255u) << 8) | (a.noDrainPrefetch ? 0x10000u : 0u))));
+    const uint32_t pol1 = uint32_t(__builtin_amdgcn_readfirstlane(int(min(max(a.thinReps, 1u), 255u) | (min(max(a.innerReps, 1u), 255u) << 8) | (a.noDrainPrefetch ? 0x10000u : 0u) |
+                                                                      (a.leafInCpp ? 0x40000u : 0u) | (a.noFusedStep ? 0x80000u : 0u) | (uint32_t(LDS_LEVELS - 1) << 20))));
+    const uint64_t polA = uint64_t(pol0) | (uint64_t(pol1) << 32);
 
 #define RACC_TOP(DEEP, dst)                                                                       \
     do {                                                                                          \
@@ -208,29 +208,40 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_
         for (;;) {
             uint32_t code;
             const uint32_t flags = uint32_t(__builtin_amdgcn_readfirstlane(int((exhausted ? 1u : 0u) | (afterLeaf << 1))));
+            const uint64_t polB = uint64_t(flags) | (uint64_t(a.maxIters) << 32);
             asm volatile(
                 // ---- entry: unpack the policy, stage addresses, constants
                 "s_mov_b64 s[40:41], exec\n\t"
-                "s_and_b32 s68, %[pol0], 0xff\n\t"              // refillMin
-                "s_bfe_u32 s69, %[pol0], 0x80008\n\t"           // leafMin
-                "s_bfe_u32 s70, %[pol0], 0x80010\n\t"           // tailActive
-                "s_lshr_b32 s71, %[pol0], 24\n\t"               // coopPct
-                "s_and_b32 s72, %[pol1], 0xff\n\t"              // thinReps
-                "s_bfe_u32 s73, %[pol1], 0x80008\n\t"           // innerReps
-                "s_and_b32 s74, %[flags], 1\n\t"                // exhausted
-                "s_lshr_b32 s63, %[flags], 1\n\t"               // first header after a C++ leaf step
+                "s_mov_b64 s[80:81], %[polA]\n\t"              // s80 = pol0, s81 = pol1
+                "s_mov_b64 s[82:83], %[polB]\n\t"              // s82 = flags, s83 = watchdog limit
+                "s_and_b32 s68, s80, 0xff\n\t"                 // refillMin
+                "s_bfe_u32 s69, s80, 0x80008\n\t"              // leafMin
+                "s_bfe_u32 s70, s80, 0x80010\n\t"              // tailActive
+                "s_lshr_b32 s71, s80, 24\n\t"                  // coopPct
+                "s_and_b32 s72, s81, 0xff\n\t"                 // thinReps
+                "s_bfe_u32 s73, s81, 0x80008\n\t"              // innerReps
+                "s_bfe_u32 s79, s81, 0x60014\n\t"              // last stack level of the LDS part
+                "s_and_b32 s74, s82, 1\n\t"                    // exhausted
+                "s_lshr_b32 s63, s82, 1\n\t"                   // first header after a leaf step
                 "s_mov_b32 s66, 0xffffff\n\t"
                 "s_add_u32 s75, %[stage], 1040\n\t"
                 "s_add_u32 s76, %[stage], 2080\n\t"
                 "s_add_u32 s77, %[stage], 3120\n\t"
+                "v_mbcnt_lo_u32_b32 v88, -1, 0\n\t"
+                "v_mbcnt_hi_u32_b32 v88, -1, v88\n\t"          // lane
+                "v_and_b32_e32 v90, 3, v88\n\t"                // lane in quad
+                "v_lshrrev_b32_e32 v87, 2, v88\n\t"
+                "v_mul_u32_u24_e32 v89, 0x410, v90\n\t"
+                "v_lshl_add_u32 v89, v87, 6, v89\n\t"
+                "v_add_u32_e32 v89, %[stage], v89\n\t"         // LDS address of this lane's record in the stage: (lane & 3) * 1040 + (lane >> 2) * 64
                 // ---- scheduling header
                 "L_top%=:\n\t"
                 "s_add_u32 %[iter], %[iter], 1\n\t"
-                "s_cmp_gt_u32 %[iter], %[maxit]\n\t"
+                "s_cmp_gt_u32 %[iter], s83\n\t"
                 "s_cbranch_scc1 L_trip%=\n\t"
                 "v_cmp_gt_i32_e64 s[42:43], 0, %[node]\n\t"             // lanes at an inner node
                 "v_cmp_lt_i32_e64 s[44:45], s66, %[node]\n\t"           // lanes at a leaf
-                "v_cmp_le_i32_e64 s[50:51], %[splim], %[sp]\n\t"        // stack within one level of the LDS part's end
+                "v_cmp_le_i32_e64 s[50:51], s79, %[sp]\n\t"        // stack within one level of the LDS part's end
                 "s_bcnt1_i32_b64 s46, s[42:43]\n\t"
                 "s_bcnt1_i32_b64 s47, s[44:45]\n\t"
                 "s_add_u32 s48, s46, s47\n\t"
@@ -288,14 +299,14 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_
                 "s_cbranch_scc1 L_coop%=\n\t"
                 "s_mov_b64 exec, s[42:43]\n\t"
                 "v_lshlrev_b32_e32 v64, 6, %[node]\n\t"                 // byte offset of the 64 B record (bit 31 falls off)
-                "v_lshl_add_u32 v63, %[sp], %[lshift], %[ldscol]\n\t"          // LDS address of the top stack entry
+                "v_lshl_add_u32 v63, %[sp], 10, %[ldscol]\n\t"          // LDS address of the top stack entry
                 "global_load_dwordx2 v[60:61], v64, %[nodes]\n\t"
                 "global_load_dwordx4 v[48:51], v64, %[nodes] offset:16\n\t"
                 "global_load_dwordx4 v[52:55], v64, %[nodes] offset:32\n\t"
                 "global_load_dwordx4 v[56:59], v64, %[nodes] offset:48\n\t"
                 "ds_read_b32 v62, v63\n\t"
                 "s_and_b32 s49, s61, s74\n\t"
-                "s_bitcmp1_b32 %[pol1], 16\n\t"                       // drain prefetch switched off?
+                "s_bitcmp1_b32 s81, 16\n\t"                       // drain prefetch switched off?
                 "s_cselect_b32 s49, 0, s49\n\t"
                 "s_cmp_lg_u32 s49, 0\n\t"
                 "s_cbranch_scc0 L_nopf%=\n\t"
@@ -333,12 +344,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_
                 "L_coop%=:\n\t"                                         // all 64 lanes: a quad fetches the record of its lane j, 16 B each
                 "s_mov_b64 exec, s[40:41]\n\t"
                 "v_lshlrev_b32_e32 v64, 2, %[node]\n\t"                 // 16 B element index of the record (lanes without an inner node: out of range or harmless)
-                "v_lshl_add_u32 v63, %[sp], %[lshift], %[ldscol]\n\t"
+                "v_lshl_add_u32 v63, %[sp], 10, %[ldscol]\n\t"
                 "s_mov_b32 m0, %[stage]\n\t"
-                "v_or_b32_dpp v65, v64, %[ql] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_or_b32_dpp v66, v64, %[ql] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_or_b32_dpp v67, v64, %[ql] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_or_b32_dpp v68, v64, %[ql] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_or_b32_dpp v65, v64, v90 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_or_b32_dpp v66, v64, v90 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_or_b32_dpp v67, v64, v90 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_or_b32_dpp v68, v64, v90 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                 "buffer_load_dwordx4 v65, %[rsrc], 0 idxen lds\n\t"
                 "s_mov_b32 m0, s75\n\t"
                 "s_nop 0\n\t"
@@ -350,11 +361,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_
                 "s_nop 0\n\t"
                 "buffer_load_dwordx4 v68, %[rsrc], 0 idxen lds\n\t"
                 "s_waitcnt vmcnt(0)\n\t"                                // the four pieces have landed in the stage
+                "L_coopread%=:\n\t"
                 "s_mov_b64 exec, s[42:43]\n\t"
-                "ds_read_b64 v[60:61], %[rec]\n\t"
-                "ds_read_b128 v[48:51], %[rec] offset:16\n\t"
-                "ds_read_b128 v[52:55], %[rec] offset:32\n\t"
-                "ds_read_b128 v[56:59], %[rec] offset:48\n\t"
+                "ds_read_b64 v[60:61], v89\n\t"
+                "ds_read_b128 v[48:51], v89 offset:16\n\t"
+                "ds_read_b128 v[52:55], v89 offset:32\n\t"
+                "ds_read_b128 v[56:59], v89 offset:48\n\t"
                 "ds_read_b32 v62, v63\n\t"
                 "s_waitcnt lgkmcnt(3)\n\t"
                 "v_pk_fma_f32 v[48:49], v[48:49], %[vix], %[vex]\n\t"
@@ -401,7 +413,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_
                 "v_cndmask_b32_e64 v71, v61, v60, s[56:57]\n\t"         // far child
                 "v_cndmask_b32_e64 v72, v60, v61, s[56:57]\n\t"         // near child
                 "v_cmp_neq_f32_e64 s[52:53], 0, v70\n\t"                // firstDiff + lastDiff != 0, Kernels.h:192
-                "ds_write_b32 v63, v71 offset:%[lstride]\n\t"                 // above the top; counts only if sp is raised below
+                "ds_write_b32 v63, v71 offset:1024\n\t"                 // above the top; counts only if sp is raised below
                 "s_and_b64 s[58:59], s[58:59], s[52:53]\n\t"
                 "s_andn2_b64 s[54:55], exec, s[52:53]\n\t"
                 "s_waitcnt lgkmcnt(1)\n\t"
@@ -412,7 +424,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_
                 "v_cmp_gt_i32_e64 s[42:43], 0, %[node]\n\t"
                 "s_cmp_eq_u32 s60, 0\n\t"
                 "s_cbranch_scc1 L_repdone%=\n\t"
-                "v_cmp_le_i32_e64 s[50:51], %[splim], %[sp]\n\t"        // (a push may have filled the LDS part)
+                "v_cmp_le_i32_e64 s[50:51], s79, %[sp]\n\t"        // (a push may have filled the LDS part)
                 "s_and_b64 s[50:51], s[50:51], s[42:43]\n\t"
                 "s_cmp_lg_u64 s[50:51], 0\n\t"
                 "s_cbranch_scc1 L_repdone%=\n\t"
@@ -431,21 +443,188 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS_
                 "L_trip%=:\n\t"
                 "s_mov_b32 %[code], 2\n\t"
                 "s_branch L_out%=\n\t"
-                "L_leaf%=:\n\t"
+                "L_leafcpp%=:\n\t"
                 "s_mov_b32 %[code], 3\n\t"
+                "s_branch L_out%=\n\t"
+                // ---- leaf step (Kernels.h:200-205 + 36-115): one pair of every lane that waits at a leaf.  The instruction
+                // sequence is hipcc's for the branch-free form of pairIntersectData (same operations, same order, same rounding).
+                "L_leaf%=:\n\t"
+                "s_bitcmp1_b32 s81, 18\n\t"
+                "s_cbranch_scc1 L_leafcpp%=\n\t"
+                // Fused step: when inner lanes exist as well, their node records are requested FIRST (cooperative LDS-DMA: the data
+                // waits in the stage, no registers), then the leaf lanes' pairs; both fetches are in flight together, the leaf
+                // body runs, then the inner lanes read their records back and take one inner step.  One memory round trip
+                // instead of two for the iteration.
+                "s_mov_b32 s67, 0\n\t"
+                "s_cmp_eq_u32 s46, 0\n\t"
+                "s_cbranch_scc1 L_leafbody%=\n\t"
+                "s_bitcmp1_b32 s81, 19\n\t"
+                "s_cbranch_scc1 L_leafbody%=\n\t"
+                "s_mov_b32 s67, 1\n\t"
+                "v_lshlrev_b32_e32 v64, 2, %[node]\n\t"
+                "s_mov_b32 m0, %[stage]\n\t"
+                "s_nop 0\n\t"
+                "v_or_b32_dpp v65, v64, v90 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_or_b32_dpp v66, v64, v90 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_or_b32_dpp v67, v64, v90 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_or_b32_dpp v68, v64, v90 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "buffer_load_dwordx4 v65, %[rsrc], 0 idxen lds\n\t"
+                "s_mov_b32 m0, s75\n\t"
+                "s_nop 0\n\t"
+                "buffer_load_dwordx4 v66, %[rsrc], 0 idxen lds\n\t"
+                "s_mov_b32 m0, s76\n\t"
+                "s_nop 0\n\t"
+                "buffer_load_dwordx4 v67, %[rsrc], 0 idxen lds\n\t"
+                "s_mov_b32 m0, s77\n\t"
+                "s_nop 0\n\t"
+                "buffer_load_dwordx4 v68, %[rsrc], 0 idxen lds\n\t"
+                "L_leafbody%=:\n\t"
+                "s_mov_b64 exec, s[44:45]\n\t"
+                "v_and_b32_e32 v86, s66, %[node]\n\t"                  // current pair
+                "v_lshl_add_u32 v85, %[sp], 10, %[ldscol]\n\t"
+                "v_mul_u32_u24_e32 v87, 48, v86\n\t"
+                "ds_read_b32 v84, v85\n\t"                             // top of the stack: the node after this leaf's last pair
+                "global_load_dwordx4 v[48:51], v87, %[pairs]\n\t"      // e1.xyz e3.x
+                "global_load_dwordx4 v[52:55], v87, %[pairs] offset:16\n\t"   // e2.xyz e3.y
+                "global_load_dwordx4 v[56:59], v87, %[pairs] offset:32\n\t"   // p0.xyz e3.z
+                "s_waitcnt vmcnt(0)\n\t"
+                "v_mul_f32_e64 v60, v50, -v53\n\t"
+                "v_mul_f32_e64 v61, v48, -v54\n\t"
+                "v_mul_f32_e64 v62, v49, -v52\n\t"
+                "v_mul_f32_e64 v63, v59, -v49\n\t"
+                "v_mul_f32_e64 v64, v51, -v50\n\t"
+                "v_mul_f32_e64 v65, v55, -v48\n\t"
+                "v_fmac_f32_e32 v60, v49, v54\n\t"                     // n1 = e1 x e2
+                "v_fmac_f32_e32 v61, v50, v52\n\t"
+                "v_fmac_f32_e32 v62, v48, v53\n\t"
+                "v_fmac_f32_e32 v63, v55, v50\n\t"                     // n2 = e3 x e1
+                "v_fmac_f32_e32 v64, v59, v48\n\t"
+                "v_fmac_f32_e32 v65, v51, v49\n\t"
+                "v_sub_f32_e32 v66, v56, %[ox]\n\t"                    // C = p0 - o
+                "v_sub_f32_e32 v67, v57, %[oy]\n\t"
+                "v_sub_f32_e32 v68, v58, %[oz]\n\t"
+                "v_mul_f32_e64 v69, %[dz], -v67\n\t"
+                "v_mul_f32_e64 v70, %[dx], -v68\n\t"
+                "v_mul_f32_e64 v71, %[dy], -v66\n\t"
+                "v_fmac_f32_e32 v69, %[dy], v68\n\t"                   // R = d x C
+                "v_fmac_f32_e32 v70, %[dz], v66\n\t"
+                "v_fmac_f32_e32 v71, %[dx], v67\n\t"
+                "v_mul_f32_e32 v72, v60, %[dx]\n\t"
+                "v_mul_f32_e32 v73, v63, %[dx]\n\t"
+                "v_mul_f32_e32 v76, v69, v48\n\t"
+                "v_mul_f32_e32 v77, v69, v52\n\t"
+                "v_mul_f32_e32 v80, v69, v51\n\t"
+                "v_mul_f32_e32 v85, v60, v66\n\t"
+                "v_mul_f32_e32 v87, v63, v66\n\t"
+                "v_fmac_f32_e32 v72, v61, %[dy]\n\t"
+                "v_fmac_f32_e32 v73, v64, %[dy]\n\t"
+                "v_fmac_f32_e32 v76, v70, v49\n\t"
+                "v_fmac_f32_e32 v77, v70, v53\n\t"
+                "v_fmac_f32_e32 v80, v70, v55\n\t"
+                "v_fmac_f32_e32 v85, v61, v67\n\t"
+                "v_fmac_f32_e32 v87, v64, v67\n\t"
+                "v_fmac_f32_e32 v72, v62, %[dz]\n\t"                   // det1 = n1 . d
+                "v_fmac_f32_e32 v73, v65, %[dz]\n\t"                   // det2 = n2 . d
+                "v_fmac_f32_e32 v76, v71, v50\n\t"                     // R . e1
+                "v_fmac_f32_e32 v77, v71, v54\n\t"                     // R . e2
+                "v_fmac_f32_e32 v80, v71, v59\n\t"                     // R . e3
+                "v_fmac_f32_e32 v85, v62, v68\n\t"                     // n1 . C
+                "v_fmac_f32_e32 v87, v65, v68\n\t"                     // n2 . C
+                "v_and_b32_e32 v74, 0x80000000, v72\n\t"
+                "v_and_b32_e32 v75, 0x80000000, v73\n\t"
+                "v_xor_b32_e32 v77, v77, v74\n\t"                      // U1
+                "v_xor_b32_e32 v78, v76, v74\n\t"                      // V1
+                "v_xor_b32_e32 v79, v76, v75\n\t"
+                "v_xor_b32_e32 v80, v80, v75\n\t"
+                "v_xor_b32_e32 v85, v85, v74\n\t"                      // T1
+                "v_xor_b32_e32 v87, v87, v75\n\t"                      // T2
+                "v_xor_b32_e32 v79, 0x80000000, v79\n\t"               // U2 = -(R . e1) ^ sgn2
+                "v_xor_b32_e32 v80, 0x80000000, v80\n\t"               // V2 = -(R . e3) ^ sgn2
+                "v_or_b32_e32 v81, v77, v78\n\t"
+                "v_sub_f32_e64 v83, |v72|, v77\n\t"
+                "v_mul_f32_e64 v61, |v72|, %[tnear]\n\t"
+                "v_mul_f32_e64 v62, |v72|, %[tfar]\n\t"
+                "v_mul_f32_e64 v63, |v73|, %[tnear]\n\t"
+                "v_mul_f32_e64 v64, |v73|, %[tfar]\n\t"
+                "v_or_b32_e32 v82, v79, v80\n\t"
+                "v_sub_f32_e64 v60, |v73|, v79\n\t"
+                "v_sub_f32_e32 v83, v83, v78\n\t"                      // W1
+                "v_sub_f32_e32 v60, v60, v80\n\t"                      // W2
+                "v_mul_f32_e64 v65, v85, |v73|\n\t"
+                "v_mul_f32_e64 v66, v87, |v72|\n\t"
+                "v_cmp_gt_i32_e64 s[52:53], 0, v81\n\t"
+                "v_cmp_le_f32_e64 s[56:57], v85, v61\n\t"
+                "v_cmp_gt_f32_e64 s[58:59], v85, v62\n\t"
+                "v_cmp_lt_f32_e64 s[54:55], v83, 0\n\t"
+                "s_or_b64 s[52:53], s[52:53], s[56:57]\n\t"
+                "s_or_b64 s[52:53], s[52:53], s[58:59]\n\t"
+                "s_or_b64 s[52:53], s[52:53], s[54:55]\n\t"            // outside the first triangle
+                "v_cmp_gt_i32_e64 s[54:55], 0, v82\n\t"
+                "v_cmp_le_f32_e64 s[56:57], v87, v63\n\t"
+                "v_cmp_gt_f32_e64 s[58:59], v87, v64\n\t"
+                "v_cmp_lt_f32_e64 s[50:51], v60, 0\n\t"
+                "s_or_b64 s[54:55], s[54:55], s[56:57]\n\t"
+                "s_or_b64 s[54:55], s[54:55], s[58:59]\n\t"
+                "s_or_b64 s[54:55], s[54:55], s[50:51]\n\t"            // outside the second triangle
+                "v_cmp_gt_f32_e64 s[56:57], v65, v66\n\t"              // T1 * |det2| > T2 * |det1|: the second one is nearer
+                "s_and_b64 s[58:59], s[52:53], s[54:55]\n\t"
+                "s_or_b64 s[56:57], s[56:57], s[52:53]\n\t"
+                "s_andn2_b64 s[58:59], exec, s[58:59]\n\t"             // lanes with a hit
+                "s_andn2_b64 s[56:57], s[56:57], s[54:55]\n\t"         // ... in the second triangle
+                "v_cndmask_b32_e64 v67, |v72|, |v73|, s[56:57]\n\t"
+                "v_cndmask_b32_e64 v68, v85, v87, s[56:57]\n\t"
+                "v_cndmask_b32_e64 v69, v77, v79, s[56:57]\n\t"
+                "v_cndmask_b32_e64 v70, v78, v80, s[56:57]\n\t"
+                "v_div_scale_f32 v71, s[50:51], v67, v67, 1.0\n\t"     // 1 / |det|, correctly rounded (hipcc's expansion)
+                "v_rcp_f32_e32 v60, v71\n\t"
+                "v_cndmask_b32_e64 v61, 0, 1, s[56:57]\n\t"
+                "v_lshl_or_b32 v61, v86, 1, v61\n\t"                   // pair * 2 + which
+                "v_fma_f32 v62, -v71, v60, 1.0\n\t"
+                "v_fmac_f32_e32 v60, v62, v60\n\t"
+                "v_div_scale_f32 v62, vcc, 1.0, v67, 1.0\n\t"
+                "v_mul_f32_e32 v63, v62, v60\n\t"
+                "v_fma_f32 v64, -v71, v63, v62\n\t"
+                "v_fmac_f32_e32 v63, v64, v60\n\t"
+                "v_fma_f32 v71, -v71, v63, v62\n\t"
+                "v_div_fmas_f32 v71, v71, v60, v63\n\t"
+                "v_div_fixup_f32 v67, v71, v67, 1.0\n\t"
+                "s_mov_b32 s49, 0x2000000\n\t"
+                "v_mul_f32_e32 v68, v68, v67\n\t"                      // t
+                "v_mul_f32_e32 v69, v69, v67\n\t"                      // u
+                "v_mul_f32_e32 v70, v70, v67\n\t"                      // v
+                "v_cmp_le_u32_e64 s[52:53], s49, %[node]\n\t"          // more pairs in this leaf
+                "v_cndmask_b32_e64 %[tfar], %[tfar], v68, s[58:59]\n\t"
+                "v_cndmask_b32_e64 %[hu], %[hu], v69, s[58:59]\n\t"
+                "v_cndmask_b32_e64 %[hv], %[hv], v70, s[58:59]\n\t"
+                "v_cndmask_b32_e64 %[hidx], %[hidx], v61, s[58:59]\n\t"
+                "v_add_u32_e32 v62, 0xff000001, %[node]\n\t"           // (count - 1, first + 1)
+                "s_andn2_b64 s[54:55], exec, s[52:53]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_cndmask_b32_e64 %[node], v84, v62, s[52:53]\n\t"    // next pair, or pop
+                "v_subb_co_u32_e64 %[sp], vcc, %[sp], 0, s[54:55]\n\t"
+                "s_cmp_lg_u32 s67, 0\n\t"
+                "s_cbranch_scc0 L_leafend%=\n\t"
+                "s_mov_b64 exec, s[42:43]\n\t"                         // fused: the inner lanes' records are in the stage (the leaf body waited vmcnt(0))
+                "s_mov_b32 s60, 1\n\t"                                 // one inner step
+                "v_lshl_add_u32 v63, %[sp], 10, %[ldscol]\n\t"
+                "s_branch L_coopread%=\n\t"
+                "L_leafend%=:\n\t"
+                "s_mov_b64 exec, s[40:41]\n\t"
+                "s_mov_b32 s63, 1\n\t"                                 // a thin wave now runs its inner lanes too
+                "s_branch L_top%=\n\t"
                 "L_out%=:\n\t"
                 "s_mov_b64 exec, s[40:41]\n\t"
-                : [node] "+v"(node), [sp] "+v"(sp), [code] "=s"(code), [iter] "+s"(iter)
-                : [tfar] "v"(tFar), [tnear] "v"(tNear), [vix] "v"(vix), [viy] "v"(viy), [viz] "v"(viz), [vex] "v"(vex), [vey] "v"(vey), [vez] "v"(vez),
-                  [ldscol] "v"(ldsCol), [rec] "v"(recAddr), [ql] "v"(quadLane),
-                  [nodes] "s"(a.nodes), [rsrc] "s"(nodeRsrc), [stage] "s"(stageAddr),
-                  [pol0] "s"(pol0), [pol1] "s"(pol1), [flags] "s"(flags), [maxit] "s"(a.maxIters), [splim] "n"(LDS_LEVELS - 1),
-                  [lshift] "n"(BLOCK == 256 ? 10 : BLOCK == 128 ? 9 : 8), [lstride] "n"(BLOCK * 4)
+                : [node] "+v"(node), [sp] "+v"(sp), [tfar] "+v"(tFar), [hidx] "+v"(hitIndex), [hu] "+v"(hitU), [hv] "+v"(hitV), [code] "=s"(code), [iter] "+s"(iter)
+                : [tnear] "v"(tNear), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz),
+                  [vix] "v"(vix), [viy] "v"(viy), [viz] "v"(viz), [vex] "v"(vex), [vey] "v"(vey), [vez] "v"(vez),
+                  [ldscol] "v"(ldsCol), [nodes] "s"(a.nodes), [pairs] "s"(a.pairs), [rsrc] "s"(nodeRsrc), [stage] "s"(stageAddr),
+                  [polA] "s"(polA), [polB] "s"(polB)
                 : "memory", "vcc", "scc",
                   "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59",
-                  "s60", "s61", "s62", "s63", "s66", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77",
+                  "s60", "s61", "s62", "s63", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s79", "s80", "s81", "s82", "s83",
                   "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
-                  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79");
+                  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+                  "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90");
             afterLeaf = 0;
             if (code == 0u) break;                                   // REFILL
             if (code == 2u) { tripped = true; break; }               // TRIP
@@ -747,11 +926,9 @@ const Variant kVariants[] = {
     {256, 10, 0, RACC_X(traverseKernelV7<256, 9, false>), false, true, 1, 2, 4 * 1040},           // 38: V7: V6 as refill-loop around work-loop (no per-iteration register copies), thin waves fetch per lane
     {256, 10, 0, RACC_X(traverseKernelV7<256, 9, true>), false, true, 1, 2, 4 * 1040},            // 39: variant 38 + statistics (debug)
     {256, 14, 0, RACC_X(traverseKernelV7<256, 13, false>), false, true, 1, 2, 4 * 1040},          // 40: V7, 12-entry LDS stack (5 workgroups per CU)
-    {256, 10, 0, traverseKernelV8<256, 9, false>, false, true, 1, 2, 4 * 1040},           // 41: V8: V7 with the header + inner steps in hand-scheduled assembly
-    {256, 10, 0, traverseKernelV8<256, 9, true>, false, true, 1, 2, 4 * 1040},            // 42: variant 41 + statistics (debug; inner-step counters stay 0)
-    {256, 14, 0, traverseKernelV8<256, 13, false>, false, true, 1, 2, 4 * 1040},          // 43: V8, 12-entry LDS stack
-    {64, 14, 0, traverseKernelV8<64, 13, false>, false, true, 1, 2, 4 * 1040},            // 44: variant 43 in one-wave workgroups: a finished wave frees its slot at once (overlapping launches)
-    {128, 14, 0, traverseKernelV8<128, 13, false>, false, true, 1, 2, 4 * 1040},          // 45: two-wave workgroups
+    {256, 10, 0, traverseKernelV8<256, 9, false>, false, true, 1, 2, 4 * 1040},           // 41: V8 with an 8-entry LDS stack (exercises the DEEP door and the spill: 2.6 % of the bench rays)
+    {256, 14, 0, traverseKernelV8<256, 13, true>, false, true, 1, 2, 4 * 1040},           // 42: variant 43 + statistics (debug; only the C++ parts count: refills, rays loaded, waves)
+    {256, 14, 0, traverseKernelV8<256, 13, false>, false, true, 1, 2, 4 * 1040},          // 43: V8, 12-entry LDS stack: the default
 };
 constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kSoaVariant = 27;
@@ -829,6 +1006,8 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.innerReps = optOr(ctx->opts.inner_reps, 3u);
     a.coopNum = ctx->opts.coop_same_pct ? (ctx->opts.coop_same_pct > 100u ? 0u : ctx->opts.coop_same_pct) : 20u;   // > 100 disables the cooperative fetch
     a.coopDen = 100u;
+    a.leafInCpp = ctx->opts.leaf_step == 2u ? 1u : 0u;
+    a.noFusedStep = ctx->opts.leaf_step == 3u ? 1u : 0u;
     a.noDrainPrefetch = ctx->opts.drain_prefetch == 1u ? 0u : 1u;      // off by default: measured -3 % on a 64k-ray batch, +4..10 % on 256k-1M
     a.stats = reinterpret_cast<unsigned long long*>(lane.cursor + 8);
     // the lane's cursor / ticket / spill serve one launch at a time: a launch on another stream than the lane's previous

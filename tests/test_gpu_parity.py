@@ -127,7 +127,7 @@ def test_launch_options_do_not_change_results(small_scene, small_host, small):
     ref = orc.traverse(small["blobs"], rays, env=small_scene["env"])
     for opt in (dict(waves_per_simd=1, refill_min=1, leaf_min=1, chunk=1), dict(waves_per_simd=8, refill_min=64, leaf_min=64, chunk=4096),
                 dict(waves_per_simd=3, refill_min=20, leaf_min=7, chunk=100), dict(lanes=1, chunk=64),
-                *[dict(kernel_variant=v) for v in ra.engine.available_variants()], *([dict(kernel_variant=18, regroup_period=3)] if 18 in ra.engine.available_variants() else []), dict(tail_active=65), dict(coop_same_pct=100), dict(coop_same_pct=101), dict(kernel_variant=41, coop_same_pct=100, refill_min=5, leaf_min=3, inner_reps=7),
+                *[dict(kernel_variant=v) for v in ra.engine.available_variants()], *([dict(kernel_variant=18, regroup_period=3)] if 18 in ra.engine.available_variants() else []), dict(tail_active=65), dict(coop_same_pct=100), dict(coop_same_pct=101), dict(kernel_variant=41, coop_same_pct=100, refill_min=5, leaf_min=3, inner_reps=7), dict(leaf_step=2), dict(leaf_step=3), dict(leaf_step=2, kernel_variant=41), dict(drain_prefetch=1),
                 dict(chunk=1 << 30), dict(thin_reps=1, inner_reps=1), dict(thin_reps=3, tail_active=40, inner_reps=2), dict(thin_reps=64, tail_active=64), dict(inner_reps=16)):
         with ra.Context(device=0, **opt) as ctx:
             scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
@@ -251,8 +251,8 @@ def test_scheduling_statistics_variant(small_scene, small_host, small):
             # and a thin wave's second body also serves lanes that changed kind in the first one, so they under-count.
             if variant == 9:
                 assert st["inner_lanes"] == int(nv.sum()) and st["leaf_lanes"] == int(npairs.sum())
-            elif variant == 42:     # V8: the inner steps run inside the assembly block and are not counted
-                assert st["leaf_lanes"] == int(npairs.sum()) and st["waves"] > 0
+            elif variant == 42:     # V8: the inner and leaf steps run inside the assembly block and are not counted
+                assert st["waves"] > 0 and st["refill_iters"] >= st["waves"]
                 scene.destroy()
                 continue
             else:
