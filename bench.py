@@ -367,6 +367,17 @@ def main():
                             "gbs": round(alg_bytes / step_s / 1e9, 1),
                             "x_hbm_peak": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
                             "note": "served by L2 / Infinity Cache, not HBM: not a fraction of any physical ceiling"},
+                        # The algorithmic bytes DO pass through each CU's vector-L1 data-return path (every node visit's 64 B,
+                        # every pair's 48 B), so that path is the ceiling they can be held to: bytes per clock per CU against
+                        # the best rate a pure gather of random 64 B records reaches on this part (tools/microbench/gather64.hip,
+                        # quad-cooperative LDS-DMA: 4 KiB per 128 cycles per CU = 32 B/clk/CU; four dwordx4 per lane: 21.9).
+                        "l1_gather": None if not alg_bytes else {
+                            "achieved_B_per_clk_per_CU": round(alg_bytes / step_s / (256 * 2.4e9), 2),
+                            "steady_state_B_per_clk_per_CU": (round(alg_bytes / ((1 << 20) / (extras["batch_scaling"]["steady_state_mrays_per_s"] * 1e6)) / (256 * 2.4e9), 2)
+                                                              if "batch_scaling" in extras else None),
+                            "measured_gather_ceiling_B_per_clk_per_CU": 32.0,
+                            "frac": round(alg_bytes / step_s / (256 * 2.4e9) / 32.0, 4),
+                            "note": "256 CUs x 2.4 GHz; ceiling = tools/microbench/gather64 mode 2 (64 random 64 B records per wave, 6 waves/SIMD)"},
                         "limiter": None if not prof else {k: prof.get(k) for k in (
                             "bound", "td_busy_frac", "ta_busy_frac", "valu_busy_frac", "issue_slot_frac", "valu_lane_util", "salu_share",
                             "l2_hit_rate", "hbm_physical_frac_isolated", "kernel_ms_isolated", "source")},
