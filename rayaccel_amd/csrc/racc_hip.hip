@@ -778,6 +778,9 @@ int validateScene(const GpuNodeHost* nodes, uint32_t nodeCount, uint32_t pairCou
                   racc_hip_scene_info& info) {
     if (!nodeCount) return fail(RACC_HIP_ERR_LIMIT, "scene has no inner node (needs >= 3 triangles; root must be inner, Kernels.h:164)");
     if (nodeCount >= 0x7FFFFFFFu || pairCount > (1u << 24)) return fail(RACC_HIP_ERR_LIMIT, "node/pair count exceeds the reference format (Scene.cpp:294-312)");
+    // the kernel addresses a node record by a 32-bit byte offset (index << 6): 2^26 inner nodes = 4 GiB of records, i.e. scenes
+    // of ~190 M triangles; the reference format's own limit on pairs (2^24, above) is reached long before
+    if (nodeCount > (1u << 26)) return fail(RACC_HIP_ERR_LIMIT, "more than 2^26 inner nodes: beyond the 32-bit record offsets of this kernel");
     std::vector<uint8_t> seen(nodeCount, 0);
     std::vector<std::pair<uint32_t, uint32_t>> work;   // (node, depth)
     work.emplace_back(0u, 1u);
@@ -962,7 +965,9 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     uint32_t wavesPerSimd = ctx->opts.waves_per_simd ? ctx->opts.waves_per_simd : lane.forceWavesPerSimd;
     if (!wavesPerSimd) {
         wavesPerSimd = 6u;
-        for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
+        // (only for batches whose drain is a visible share of the launch: the device-resident path tracer's 16M-ray bounces run
+        //  3.42 Grays/s end to end with full grids, 3.08 with halved ones)
+        for (uint32_t i = 0; i < ctx->opts.lanes && count <= (2u << 20); ++i) {
             const Lane& other = ctx->lanes[i];
             if (&other != &lane && other.everLaunched.load(std::memory_order_relaxed) && hipEventQuery(other.done) == hipErrorNotReady) { wavesPerSimd = 3u; break; }
         }
