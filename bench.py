@@ -77,8 +77,8 @@ def usable_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", choices=("weak", "strong"), default="weak",
                     help="weak (default): 1M rays per GPU per step; strong: one 8M-ray batch per step cut into N shards (configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
@@ -157,6 +157,8 @@ def main():
         ctx.wait(ra.LANE_AUTO)
 
     def drain_kernel_times():
+        if not engine_opts.get("time_kernels"):
+            return []
         return [t for lane in range(lanes) for t in ctx.kernel_times(lane)]
 
     if args.warmup:
