@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", choices=("weak", "strong"), default="weak",
                     help="weak (default): 1M rays per GPU per step; strong: one 8M-ray batch per step cut into N shards (configs[3])")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: also time the K steps with the RCCL all-gather of every step's hit records (racc_hip_allgather_results); implied by --mode strong")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (profiling runs)")
     ap.add_argument("--grid", type=int, default=700, help="height-field resolution of battlefield-synth (700 = full)")
@@ -184,7 +186,8 @@ def main():
 
     # ---- optional extras, all outside the timed region ------------------------------------------
     extras = {}
-    if world > 1 and backend == "nccl":
+    if world > 1 and backend == "nccl" and (args.gather or args.mode == "strong"):
+        # (opt-in: the default line must not depend on a second collective library instance coming up on every rank)
         # RCCL all-gather of the Result shards over xGMI through the C-ABI's own entry (racc_hip_allgather_results binds
         # librccl; only a GPU-side consumer that needs every hit on every GPU needs it).  Second timed figure: the same K
         # steps with the gather of every step's results inside the region.

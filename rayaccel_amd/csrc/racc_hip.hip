@@ -1611,7 +1611,18 @@ RcclApi* rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        // a copy the process already loaded (torch.distributed ships its own) first, then the ROCm one
+        // a copy the process already mapped (torch.distributed ships its own: one RCCL instance per process, not two) first,
+        // then the ROCm one
+        if (FILE* maps = std::fopen("/proc/self/maps", "r")) {
+            char line[1024];
+            while (!api.lib && std::fgets(line, sizeof(line), maps)) {
+                char* path = std::strchr(line, '/');
+                if (!path || !std::strstr(path, "librccl")) continue;
+                path[std::strcspn(path, "\n")] = 0;
+                api.lib = dlopen(path, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            }
+            std::fclose(maps);
+        }
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
         for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);

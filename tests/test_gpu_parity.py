@@ -401,3 +401,25 @@ def test_config3_8M_rays_in_8_shards(gpu_ctx, full):
     comm.destroy()
     for d in (d_r, d_all, d_sh, d_g):
         d.free()
+
+
+def test_api_misuse_is_reported_not_fatal(gpu_ctx, small):
+    """Error paths of the round-2 entries: each returns a status and text, none aborts."""
+    lib = ra.load_library()
+    with pytest.raises(ra.RaccError) as e:
+        gpu_ctx.kernel_times(0)                                  # context created without time_kernels
+    assert e.value.code == -1
+    with pytest.raises(ra.RaccError):
+        ra.Context(device=0, kernel_variant=1000)
+    if 22 not in ra.engine.available_variants():
+        with pytest.raises(ra.RaccError) as e:
+            ra.Context(device=0, kernel_variant=22)              # an experimental kernel in a shipped build
+        assert "EXPERIMENTAL" in str(e.value)
+    with pytest.raises(ra.RaccError):
+        ra.Comm(gpu_ctx, ra.Comm.unique_id(), 3, 2)              # rank outside the world
+    with pytest.raises(ra.RaccError):
+        gpu_ctx.intersect_device(small["scene"], small["env"], 0, 0, 64, lane=ra.LANE_AUTO)      # null device pointers
+    with pytest.raises(ra.RaccError):
+        gpu_ctx.intersect_device(small["scene"], small["env"], 1, 1, 64, lane=17)                 # lane out of range
+    rays = small["primary"][:1000]
+    assert_bit_exact(gpu_ctx.intersect(small["scene"], small["env"], rays), orc.traverse(small["blobs"], rays, env=small["sc"]["env"]), "after the misuse")
