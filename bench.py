@@ -31,7 +31,7 @@ HBM_MEASURED_GBS = 6290.0      # same guide: float4-copy ceiling
 RAYS_PER_BATCH = 1 << 20
 KERNEL_NAME = "traverseKernelV8"
 PROFILE_DIR = os.path.join("profiles", "r02")      # rocprofv3 summaries of THIS command (tools/profile_bench.sh r02)
-KERNEL_SOURCES = ("rayaccel_amd/csrc/racc_hip.hip", "rayaccel_amd/csrc/racc_device.inc")
+KERNEL_SOURCES = ("rayaccel_amd/csrc/racc_kernel_v8.inc", "rayaccel_amd/csrc/racc_device.inc")
 
 
 def kernel_source_sha256():

@@ -9,15 +9,15 @@
 //   * each iteration the wave VOTES on what to run: an inner-node step for every lane that holds an inner node, or a
 //     triangle-pair step for every lane that holds a leaf ("vote-scheduled while-while"); Moller-Trumbore (the
 //     reference's Embree-style pair test, Kernels.h:36-115) is fused into that leaf step;
-//   * the per-ray traversal stack lives in LDS as [level][thread] (bank = thread % 32 at every level, so pushes/pops never
-//     conflict), sized from the real tree height at upload time, with a global-memory spill instantiation for tall trees
-//     — unlike the reference's unchecked stack[64] it cannot overflow;
+//   * divergent waves fetch their 64 B node records quad-cooperatively through LDS-DMA (four lanes read one record's 64
+//     contiguous bytes); the per-ray traversal stack lives in LDS as [level][thread] (12 entries, conflict-free), deeper
+//     entries in a global spill — unlike the reference's unchecked stack[64] it cannot overflow;
 //   * hit epilogues (remap gather + barycentric rotation) are batched into the refill step; miss radiance is evaluated by
-//     a second, streaming kernel (envShadeKernel).
-// traverseKernelV2 below is the shipped kernel (thin-wave drain policy, lazy epilogues, deferred miss shading, static
-// first chunk, while-while inner repeats).  Three other generations — V1 (the first correct kernel, optional LDS cache of
-// the top of the tree), V3 (workgroup-wide regrouping through LDS) and V4 (two rays per lane) — live in
-// racc_kernels_experimental.inc and stay selectable through racc_hip_options::kernel_variant.
+//     a second, streaming kernel (envShadeKernel);
+//   * launches of different lanes (HIP stream + ray cursor + spill area each) overlap: one's drain runs beside the next
+//     one's bulk.
+// The shipped kernel, traverseKernelV8 (hot loop in hand-scheduled assembly), is in racc_kernel_v8.inc; the seven earlier
+// generations are in racc_kernels_experimental.inc and exist only in a `make EXPERIMENTAL=1` build.
 // Arithmetic is IEEE binary32 with explicit fmaf only (built with -ffp-contract=off, no fast-math), the same evaluation
 // order as oracle/racc_oracle.c, so primId/t/u/v are bit-identical to the CPU restatement for every finite ray.  The
 // traversal ORDER is the reference's (nearer child first, far child pushed only if both hit, pairs of a leaf in order),
@@ -46,640 +46,7 @@ namespace {
 
 #include "racc_device.inc"
 
-// ================================================================================================ V8
-// V7's algorithm with the hot part — the scheduling header and the inner steps — written as one hand-scheduled assembly
-// block.  hipcc turns that part's wave-uniform control into exec-masked vector code, routes uniform flags through VGPRs and
-// copies six state registers per iteration; here a header is 4 VALU + ~25 SALU, an inner step 44 (per-lane fetch) or 48
-// (quad-cooperative fetch) VALU and ~12 SALU, nothing is copied.  The block leaves through four doors:
-//   REFILL  enough idle lanes (or nothing to do): the C++ above it runs the epilogue/refill
-//   LEAF    the vote asks for a leaf step: C++ runs pairIntersectData on the leaf lanes and comes back
-//   DEEP    an active lane's stack is within one level of the end of its LDS part: C++ runs one spill-aware iteration
-//   TRIP    watchdog
-// Arithmetic and order are V7's (the slab sequence is hipcc's own instruction sequence for slabPairV), so results stay
-// bit-identical.  Software wait states follow LLVM's GCNHazardRecognizer for gfx940+: VALU-written SGPR/VCC -> VALU read 2,
-// VALU-written VGPR -> DPP read 2, s_mov m0 -> LDS-DMA 1.
-template <int BLOCK, int LDS_LEVELS, bool STATS>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) traverseKernelV8(const TraverseArgs a) {
-    static_assert(BLOCK == 256, "the assembly block addresses the stack with literal strides (level = 1 KiB)");
-    constexpr uint32_t kStagePiece = 1040u;
-    __shared__ uint32_t lds[(LDS_LEVELS + 1) * BLOCK];
-    __shared__ __attribute__((aligned(16))) unsigned char stageAll[(BLOCK / 64) * 4 * kStagePiece];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6)));
-    uint32_t* const myLds = lds + tid;
-    uint32_t* const mySpill = a.spill + (blockIdx.x * BLOCK + tid);      // level L >= LDS_LEVELS lives at mySpill[(L - LDS_LEVELS) * spillStride]
-    unsigned char* const stage = stageAll + wave * 4u * kStagePiece;
-    typedef __attribute__((address_space(3))) unsigned char* lbyte_t;
-    const uint32_t ldsCol = uint32_t(reinterpret_cast<uintptr_t>((lbyte_t)(reinterpret_cast<unsigned char*>(myLds))));            // LDS byte address of level 0
-    const uint32_t stageAddr = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(reinterpret_cast<uintptr_t>((lbyte_t)stage)))));
-    const __amdgpu_buffer_rsrc_t nodeRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.nodes), 16, a.nodeCount * 4u, 0x00020000);
-    myLds[0] = kDone;           // the sentinel below every ray's stack (own column: no barrier needed)
-
-    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, tNear = 0.f, tFar = 0.f, hitU = 0.f, hitV = 0.f;
-    f32x2 vix = {0.f, 0.f}, viy = vix, viz = vix, vex = vix, vey = vix, vez = vix;
-    int hitIndex = -1;
-    uint32_t rayIdx = 0;
-    uint32_t node = kEmpty;     // bit31: inner ref | >= kLeafBase: leaf, pairs pending | kDone: awaiting epilogue | kEmpty
-    uint32_t sp = 0;            // level of the top stack entry (0 = only the sentinel)
-    uint32_t wBeg = min((blockIdx.x * uint32_t(BLOCK / 64) + wave) * a.chunk, a.count);
-    uint32_t wEnd = min(wBeg + a.chunk, a.count);
-    bool exhausted = false;
-    uint32_t iter = 0;
-    uint32_t stInner = 0, stInnerLanes = 0, stLeaf = 0, stLeafLanes = 0, stRefill = 0, stLoaded = 0, stDeq = 0;
-    unsigned long long cyInner = 0, cyLeaf = 0, cyRefill = 0, cyStart = 0;
-    if (STATS) cyStart = __builtin_readcyclecounter();
-    // policy words for the assembly block: [refillMin | leafMin << 8 | tailActive << 16 | coopPct << 24], [thinReps | innerReps << 8]
-    const uint32_t pol0 = uint32_t(__builtin_amdgcn_readfirstlane(int(min(a.refillMin, 255u) | (min(a.leafMin, 255u) << 8) | (min(a.tailActive, 255u) << 16) | (min(a.coopNum, 255u) << 24))));
-    const uint32_t pol1 = uint32_t(__builtin_amdgcn_readfirstlane(int(min(max(a.thinReps, 1u), 255u) | (min(max(a.innerReps, 1u), 255u) << 8) | (a.noDrainPrefetch ? 0x10000u : 0u) |
-                                                                      (a.leafInCpp ? 0x40000u : 0u) | (a.noFusedStep ? 0x80000u : 0u) | (uint32_t(LDS_LEVELS - 1) << 20))));
-    const uint64_t polA = uint64_t(pol0) | (uint64_t(pol1) << 32);
-
-#define RACC_TOP(DEEP, dst)                                                                       \
-    do {                                                                                          \
-        if (!(DEEP)) { dst = myLds[sp * BLOCK]; }                                                 \
-        else {                                                                                    \
-            dst = myLds[min(sp, uint32_t(LDS_LEVELS)) * BLOCK];                                   \
-            if (sp >= uint32_t(LDS_LEVELS)) {                                                     \
-                uint32_t s_ = mySpill[size_t(sp - LDS_LEVELS) * a.spillStride];                   \
-                asm volatile("" : "+v"(s_));   /* keeps the two address spaces apart (no flat_load of a selected pointer) */ \
-                dst = s_;                                                                         \
-            }                                                                                     \
-        }                                                                                         \
-    } while (0)
-#define RACC_ABOVE(DEEP, v, counts)                                                               \
-    do {                                                                                          \
-        const uint32_t l_ = sp + 1u;                                                              \
-        if (!(DEEP)) { myLds[l_ * BLOCK] = (v); }                                                 \
-        else {                                                                                    \
-            myLds[min(l_, uint32_t(LDS_LEVELS)) * BLOCK] = (v);                                   \
-            if (l_ >= uint32_t(LDS_LEVELS) && (counts)) mySpill[size_t(l_ - LDS_LEVELS) * a.spillStride] = (v); \
-        }                                                                                         \
-    } while (0)
-    // one pair of every lane that waits at a leaf (Kernels.h:200-205 + 36-115); DEEP: the pop may come from the spill
-#define RACC_LEAF_STEP(DEEP)                                                                      \
-    do {                                                                                          \
-        if (int(node) >= int(kLeafBase)) {                                                        \
-            const uint32_t cur = node & 0xFFFFFFu;                                                \
-            const float4 t0 = a.pairs[cur * 3u], t1 = a.pairs[cur * 3u + 1u], t2 = a.pairs[cur * 3u + 2u]; \
-            uint32_t popped;                                                                      \
-            RACC_TOP(DEEP, popped);                                                               \
-            LaneRay r;                                                                            \
-            r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz; r.tNear = tNear; r.tFar = tFar; \
-            r.hitIndex = hitIndex; r.hitU = hitU; r.hitV = hitV;                                  \
-            tFar = pairIntersectData(t0, t1, t2, cur, r);                                         \
-            hitIndex = r.hitIndex; hitU = r.hitU; hitV = r.hitV;                                  \
-            const bool more = node >= 2u * kLeafBase;          /* pair count > 1 */               \
-            node = more ? node - 0xFFFFFFu : popped;           /* (count - 1, first + 1) | pop */ \
-            sp -= more ? 0u : 1u;                                                                 \
-        }                                                                                         \
-    } while (0)
-
-    bool tripped = false;
-    for (;;) {
-        // ================= epilogue of finished rays + refill of empty lanes =================
-        unsigned long long cyTop = 0;
-        if (STATS) { cyTop = __builtin_readcyclecounter(); ++stRefill; }
-        if (node == kDone) {     // Kernels.h:213-241
-            float4 out;
-            if (hitIndex < 0) {
-                out = a.env ? make_float4(__uint_as_float(kInvalidTriangle), dx, dy, dz)
-                            : make_float4(__uint_as_float(kInvalidTriangle), 0.0f, 0.0f, 0.0f);
-            } else {
-                uint32_t m = a.remap[hitIndex];
-                const uint32_t edge = m >> 30;
-                m &= 0x3FFFFFFFu;
-                const float bx = hitU, by = hitV, bz = 1.0f - hitU - hitV;
-                float u = bx, v = by;
-                if (edge == 1u) { u = bz; v = bx; } else if (edge == 2u) { u = by; v = bz; }
-                out = make_float4(__uint_as_float(m), tFar, u, v);
-            }
-            a.results[rayIdx] = out;
-            node = kEmpty;
-        }
-        {
-            const uint64_t emptyMask = __ballot(node == kEmpty);
-            const uint32_t need = __popcll(emptyMask);
-            if (wBeg == wEnd && !exhausted) {
-                if (STATS) ++stDeq;
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(a.cursor, a.chunk);
-                const uint32_t r0 = __builtin_amdgcn_readfirstlane(b);
-                b = r0 + gridDim.x * uint32_t(BLOCK / 64) * a.chunk;      // (the grid's first chunks are static)
-                if (b < r0) b = 0xFFFFFFFFu;      // 32-bit wrap: past any batch
-                exhausted = (b >= a.count) || (b + a.chunk < b);
-                wBeg = exhausted ? a.count : b;
-                wEnd = exhausted ? a.count : min(b + a.chunk, a.count);
-            }
-            const uint32_t take = min(need, wEnd - wBeg);
-            const uint32_t rank = laneRank(emptyMask);
-            if (node == kEmpty && rank < take) {
-                const uint32_t idx = wBeg + rank;
-                const float4 q0 = a.rays[size_t(idx) * 2 + 0];
-                const float4 q1 = a.rays[size_t(idx) * 2 + 1];
-                const bool valid = isfinite(q0.x) && isfinite(q0.y) && isfinite(q0.z) && isfinite(q0.w) &&
-                                   isfinite(q1.x) && isfinite(q1.y) && isfinite(q1.z) && !isnan(q1.w);
-                if (!valid) {   // NaN in the first slot tells envShadeKernel to leave rgb = 0
-                    a.results[idx] = make_float4(__uint_as_float(kInvalidTriangle), a.env ? __uint_as_float(0x7FC00000u) : 0.0f, 0.0f, 0.0f);
-                } else {
-                    const float eps = 1e-10f;   // Kernels.h:149-157
-                    ox = q0.x; oy = q0.y; oz = q0.z; tNear = q0.w;
-                    dx = (fabsf(q1.x) < eps) ? copysignf(eps, q1.x) : q1.x;
-                    dy = (fabsf(q1.y) < eps) ? copysignf(eps, q1.y) : q1.y;
-                    dz = (fabsf(q1.z) < eps) ? copysignf(eps, q1.z) : q1.z;
-                    tFar = q1.w;
-                    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;    // Kernels.h:159-160
-                    const float ex = -ox * ix, ey = -oy * iy, ez = -oz * iz;
-                    vix = (f32x2){ix, ix}; viy = (f32x2){iy, iy}; viz = (f32x2){iz, iz};
-                    vex = (f32x2){ex, ex}; vey = (f32x2){ey, ey}; vez = (f32x2){ez, ez};
-                    hitIndex = -1; hitU = 0.0f; hitV = 0.0f;
-                    rayIdx = idx;
-                    node = 0x80000000u;     // Kernels.h:164
-                    sp = 0;
-                }
-            }
-            wBeg += take;
-            if (STATS) { stLoaded += take; cyRefill += __builtin_readcyclecounter() - cyTop; }
-            if (exhausted && wBeg == wEnd && __ballot(node != kEmpty) == 0ull) break;
-        }
-
-        // ================= traverse until a refill is due =================
-        uint32_t afterLeaf = 0;
-        for (;;) {
-            uint32_t code;
-            const uint32_t flags = uint32_t(__builtin_amdgcn_readfirstlane(int((exhausted ? 1u : 0u) | (afterLeaf << 1))));
-            const uint64_t polB = uint64_t(flags) | (uint64_t(a.maxIters) << 32);
-            asm volatile(
-                // ---- entry: unpack the policy, stage addresses, constants
-                "s_mov_b64 s[40:41], exec\n\t"
-                "s_mov_b64 s[80:81], %[polA]\n\t"              // s80 = pol0, s81 = pol1
-                "s_mov_b64 s[82:83], %[polB]\n\t"              // s82 = flags, s83 = watchdog limit
-                "s_and_b32 s68, s80, 0xff\n\t"                 // refillMin
-                "s_bfe_u32 s69, s80, 0x80008\n\t"              // leafMin
-                "s_bfe_u32 s70, s80, 0x80010\n\t"              // tailActive
-                "s_lshr_b32 s71, s80, 24\n\t"                  // coopPct
-                "s_and_b32 s72, s81, 0xff\n\t"                 // thinReps
-                "s_bfe_u32 s73, s81, 0x80008\n\t"              // innerReps
-                "s_bfe_u32 s79, s81, 0x60014\n\t"              // last stack level of the LDS part
-                "s_and_b32 s74, s82, 1\n\t"                    // exhausted
-                "s_lshr_b32 s63, s82, 1\n\t"                   // first header after a leaf step
-                "s_mov_b32 s66, 0xffffff\n\t"
-                "s_add_u32 s75, %[stage], 1040\n\t"
-                "s_add_u32 s76, %[stage], 2080\n\t"
-                "s_add_u32 s77, %[stage], 3120\n\t"
-                "v_mbcnt_lo_u32_b32 v88, -1, 0\n\t"
-                "v_mbcnt_hi_u32_b32 v88, -1, v88\n\t"          // lane
-                "v_and_b32_e32 v90, 3, v88\n\t"                // lane in quad
-                "v_lshrrev_b32_e32 v87, 2, v88\n\t"
-                "v_mul_u32_u24_e32 v89, 0x410, v90\n\t"
-                "v_lshl_add_u32 v89, v87, 6, v89\n\t"
-                "v_add_u32_e32 v89, %[stage], v89\n\t"         // LDS address of this lane's record in the stage: (lane & 3) * 1040 + (lane >> 2) * 64
-                // ---- scheduling header
-                "L_top%=:\n\t"
-                "s_add_u32 %[iter], %[iter], 1\n\t"
-                "s_cmp_gt_u32 %[iter], s83\n\t"
-                "s_cbranch_scc1 L_trip%=\n\t"
-                "v_cmp_gt_i32_e64 s[42:43], 0, %[node]\n\t"             // lanes at an inner node
-                "v_cmp_lt_i32_e64 s[44:45], s66, %[node]\n\t"           // lanes at a leaf
-                "v_cmp_le_i32_e64 s[50:51], s79, %[sp]\n\t"        // stack within one level of the LDS part's end
-                "s_bcnt1_i32_b64 s46, s[42:43]\n\t"
-                "s_bcnt1_i32_b64 s47, s[44:45]\n\t"
-                "s_add_u32 s48, s46, s47\n\t"
-                "s_cmp_eq_u32 s48, 0\n\t"
-                "s_cbranch_scc1 L_refill%=\n\t"
-                "s_cmp_lg_u32 s74, 0\n\t"
-                "s_cbranch_scc1 L_exh%=\n\t"
-                "s_sub_u32 s49, 64, s48\n\t"
-                "s_cmp_ge_u32 s49, s68\n\t"
-                "s_cbranch_scc1 L_refill%=\n\t"
-                "s_branch L_vote%=\n\t"
-                "L_exh%=:\n\t"
-                "v_cmp_eq_u32_e32 vcc, 1, %[node]\n\t"                  // finished rays waiting for their epilogue
-                "s_bcnt1_i32_b64 s49, vcc\n\t"
-                "s_cmp_ge_u32 s49, s68\n\t"
-                "s_cbranch_scc1 L_refill%=\n\t"
-                "L_vote%=:\n\t"
-                "s_or_b64 s[52:53], s[42:43], s[44:45]\n\t"
-                "s_and_b64 s[50:51], s[50:51], s[52:53]\n\t"
-                "s_cmp_lg_u64 s[50:51], 0\n\t"
-                "s_cbranch_scc1 L_deep%=\n\t"
-                "s_cmp_le_u32 s48, s70\n\t"
-                "s_cselect_b32 s61, 1, 0\n\t"                           // thin wave
-                "s_cmp_ge_u32 s47, s69\n\t"
-                "s_cbranch_scc1 L_wantleaf%=\n\t"
-                "s_cmp_eq_u32 s46, 0\n\t"
-                "s_cbranch_scc1 L_wantleaf%=\n\t"
-                "s_lshl_b32 s49, s47, 2\n\t"
-                "s_cmp_ge_u32 s49, s48\n\t"
-                "s_cbranch_scc0 L_inner%=\n\t"
-                "L_wantleaf%=:\n\t"                                     // a thin wave just back from its leaf step runs its inner lanes too
-                "s_and_b32 s49, s63, s61\n\t"
-                "s_cmp_lg_u32 s49, 0\n\t"
-                "s_cselect_b32 s49, s46, 0\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
-                "s_cbranch_scc1 L_leaf%=\n\t"
-                "L_inner%=:\n\t"
-                "s_mov_b32 s63, 0\n\t"
-                "s_cmp_lg_u32 s61, 0\n\t"
-                "s_cselect_b32 s60, s72, s73\n\t"                       // inner steps this iteration
-                // fetch mode: cooperative unless thin or coherent (lanes holding the same node as their quad neighbour)
-                "v_mov_b32_dpp v64, %[node] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_cmp_eq_u32_e32 vcc, v64, %[node]\n\t"
-                "s_and_b64 vcc, vcc, s[42:43]\n\t"
-                "s_bcnt1_i32_b64 s49, vcc\n\t"
-                "s_mul_i32 s49, s49, 100\n\t"
-                "s_mul_i32 s62, s46, s71\n\t"
-                "s_cmp_lt_u32 s49, s62\n\t"
-                "s_cselect_b32 s62, 1, 0\n\t"
-                "s_cmp_lg_u32 s61, 0\n\t"
-                "s_cselect_b32 s62, 0, s62\n\t"
-                // ---- inner step (Kernels.h:170-199 + 117-135)
-                "L_rep%=:\n\t"
-                "s_cmp_lg_u32 s62, 0\n\t"
-                "s_cbranch_scc1 L_coop%=\n\t"
-                "s_mov_b64 exec, s[42:43]\n\t"
-                "v_lshlrev_b32_e32 v64, 6, %[node]\n\t"                 // byte offset of the 64 B record (bit 31 falls off)
-                "v_lshl_add_u32 v63, %[sp], 10, %[ldscol]\n\t"          // LDS address of the top stack entry
-                "global_load_dwordx2 v[60:61], v64, %[nodes]\n\t"
-                "global_load_dwordx4 v[48:51], v64, %[nodes] offset:16\n\t"
-                "global_load_dwordx4 v[52:55], v64, %[nodes] offset:32\n\t"
-                "global_load_dwordx4 v[56:59], v64, %[nodes] offset:48\n\t"
-                "ds_read_b32 v62, v63\n\t"
-                "s_and_b32 s49, s61, s74\n\t"
-                "s_bitcmp1_b32 s81, 16\n\t"                       // drain prefetch switched off?
-                "s_cselect_b32 s49, 0, s49\n\t"
-                "s_cmp_lg_u32 s49, 0\n\t"
-                "s_cbranch_scc0 L_nopf%=\n\t"
-                // thin wave of an exhausted batch (the launch's drain): bound by the latency of the dependent fetch chain.  As soon as the child refs are in,
-                // touch BOTH children's records (16 B LDS-DMA loads into the unused stage: no destination register, never
-                // waited for) — the next step's fetch of the near child then finds the line on its way instead of starting
-                // the round trip after the ~40 instructions of the slab tests; the far child is warm when it is popped.
-                "s_mov_b32 m0, %[stage]\n\t"
-                "s_waitcnt vmcnt(3)\n\t"
-                "v_lshlrev_b32_e32 v65, 2, v60\n\t"                    // 16 B element index of the child's record; leaf refs fall out of range
-                "v_lshlrev_b32_e32 v66, 2, v61\n\t"
-                "buffer_load_dword v65, %[rsrc], 0 idxen lds\n\t"
-                "buffer_load_dword v66, %[rsrc], 0 idxen lds\n\t"
-                "s_waitcnt vmcnt(4)\n\t"
-                "v_pk_fma_f32 v[48:49], v[48:49], %[vix], %[vex]\n\t"
-                "v_pk_fma_f32 v[50:51], v[50:51], %[viy], %[vey]\n\t"
-                "s_waitcnt vmcnt(3)\n\t"
-                "v_pk_fma_f32 v[52:53], v[52:53], %[viz], %[vez]\n\t"
-                "v_pk_fma_f32 v[54:55], v[54:55], %[vix], %[vex]\n\t"
-                "s_waitcnt vmcnt(2)\n\t"
-                "v_pk_fma_f32 v[56:57], v[56:57], %[viy], %[vey]\n\t"
-                "v_pk_fma_f32 v[58:59], v[58:59], %[viz], %[vez]\n\t"
-                "s_branch L_tail%=\n\t"
-                "L_nopf%=:\n\t"
-                "s_waitcnt vmcnt(2)\n\t"
-                "v_pk_fma_f32 v[48:49], v[48:49], %[vix], %[vex]\n\t"
-                "v_pk_fma_f32 v[50:51], v[50:51], %[viy], %[vey]\n\t"
-                "s_waitcnt vmcnt(1)\n\t"
-                "v_pk_fma_f32 v[52:53], v[52:53], %[viz], %[vez]\n\t"
-                "v_pk_fma_f32 v[54:55], v[54:55], %[vix], %[vex]\n\t"
-                "s_waitcnt vmcnt(0)\n\t"
-                "v_pk_fma_f32 v[56:57], v[56:57], %[viy], %[vey]\n\t"
-                "v_pk_fma_f32 v[58:59], v[58:59], %[viz], %[vez]\n\t"
-                "s_branch L_tail%=\n\t"
-                "L_coop%=:\n\t"                                         // all 64 lanes: a quad fetches the record of its lane j, 16 B each
-                "s_mov_b64 exec, s[40:41]\n\t"
-                "v_lshlrev_b32_e32 v64, 2, %[node]\n\t"                 // 16 B element index of the record (lanes without an inner node: out of range or harmless)
-                "v_lshl_add_u32 v63, %[sp], 10, %[ldscol]\n\t"
-                "s_mov_b32 m0, %[stage]\n\t"
-                "v_or_b32_dpp v65, v64, v90 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_or_b32_dpp v66, v64, v90 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_or_b32_dpp v67, v64, v90 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_or_b32_dpp v68, v64, v90 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "buffer_load_dwordx4 v65, %[rsrc], 0 idxen lds\n\t"
-                "s_mov_b32 m0, s75\n\t"
-                "s_nop 0\n\t"
-                "buffer_load_dwordx4 v66, %[rsrc], 0 idxen lds\n\t"
-                "s_mov_b32 m0, s76\n\t"
-                "s_nop 0\n\t"
-                "buffer_load_dwordx4 v67, %[rsrc], 0 idxen lds\n\t"
-                "s_mov_b32 m0, s77\n\t"
-                "s_nop 0\n\t"
-                "buffer_load_dwordx4 v68, %[rsrc], 0 idxen lds\n\t"
-                "s_waitcnt vmcnt(0)\n\t"                                // the four pieces have landed in the stage
-                "L_coopread%=:\n\t"
-                "s_mov_b64 exec, s[42:43]\n\t"
-                "ds_read_b64 v[60:61], v89\n\t"
-                "ds_read_b128 v[48:51], v89 offset:16\n\t"
-                "ds_read_b128 v[52:55], v89 offset:32\n\t"
-                "ds_read_b128 v[56:59], v89 offset:48\n\t"
-                "ds_read_b32 v62, v63\n\t"
-                "s_waitcnt lgkmcnt(3)\n\t"
-                "v_pk_fma_f32 v[48:49], v[48:49], %[vix], %[vex]\n\t"
-                "v_pk_fma_f32 v[50:51], v[50:51], %[viy], %[vey]\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_pk_fma_f32 v[52:53], v[52:53], %[viz], %[vez]\n\t"
-                "v_pk_fma_f32 v[54:55], v[54:55], %[vix], %[vex]\n\t"
-                "s_waitcnt lgkmcnt(1)\n\t"
-                "v_pk_fma_f32 v[56:57], v[56:57], %[viy], %[vey]\n\t"
-                "v_pk_fma_f32 v[58:59], v[58:59], %[viz], %[vez]\n\t"
-                "L_tail%=:\n\t"                                         // hipcc's sequence for slabPairV from here on
-                "v_min_f32_e32 v69, v48, v49\n\t"
-                "v_min_f32_e32 v70, v50, v51\n\t"
-                "v_min_f32_e32 v71, v52, v53\n\t"
-                "v_max_f32_e32 v72, v48, v49\n\t"
-                "v_max_f32_e32 v73, v50, v51\n\t"
-                "v_max_f32_e32 v74, v52, v53\n\t"
-                "v_min_f32_e32 v75, v54, v55\n\t"
-                "v_min_f32_e32 v76, v56, v57\n\t"
-                "v_min_f32_e32 v77, v58, v59\n\t"
-                "v_max_f32_e32 v78, v54, v55\n\t"
-                "v_max_f32_e32 v79, v56, v57\n\t"
-                "v_max_f32_e32 v48, v58, v59\n\t"
-                "v_max_f32_e32 v70, v70, v71\n\t"
-                "v_min_f32_e32 v73, v73, v74\n\t"
-                "v_max_f32_e32 v76, v76, v77\n\t"
-                "v_min_f32_e32 v79, v79, v48\n\t"
-                "v_max3_f32 v69, %[tnear], v69, v70\n\t"                // l0
-                "v_min3_f32 v72, %[tfar], v72, v73\n\t"                 // l1
-                "v_max3_f32 v75, %[tnear], v75, v76\n\t"                // r0
-                "v_min3_f32 v78, %[tfar], v78, v79\n\t"                 // r1
-                "v_cmp_gt_f32_e32 vcc, v69, v72\n\t"
-                "v_cmp_gt_f32_e64 s[54:55], v75, v78\n\t"
-                "s_nop 1\n\t"
-                "v_cndmask_b32_e32 v69, v69, %[tfar], vcc\n\t"          // tFirst (tFar doubles as "missed", Kernels.h:131-134)
-                "v_cndmask_b32_e64 v75, v75, %[tfar], s[54:55]\n\t"     // tLast
-                "v_sub_f32_e32 v70, %[tfar], v69\n\t"
-                "v_sub_f32_e32 v71, %[tfar], v75\n\t"
-                "v_cmp_lt_f32_e64 s[56:57], v75, v69\n\t"               // lastNearer: signbit(tLast - tFirst), Kernels.h:193
-                "v_cmp_neq_f32_e64 s[54:55], v69, %[tfar]\n\t"
-                "v_cmp_neq_f32_e32 vcc, v75, %[tfar]\n\t"
-                "v_add_f32_e32 v70, v70, v71\n\t"
-                "s_and_b64 s[58:59], s[54:55], vcc\n\t"                 // fmax(tFirst, tLast) != tRay, Kernels.h:194
-                "v_cndmask_b32_e64 v71, v61, v60, s[56:57]\n\t"         // far child
-                "v_cndmask_b32_e64 v72, v60, v61, s[56:57]\n\t"         // near child
-                "v_cmp_neq_f32_e64 s[52:53], 0, v70\n\t"                // firstDiff + lastDiff != 0, Kernels.h:192
-                "ds_write_b32 v63, v71 offset:1024\n\t"                 // above the top; counts only if sp is raised below
-                "s_and_b64 s[58:59], s[58:59], s[52:53]\n\t"
-                "s_andn2_b64 s[54:55], exec, s[52:53]\n\t"
-                "s_waitcnt lgkmcnt(1)\n\t"
-                "v_cndmask_b32_e64 %[node], v62, v72, s[52:53]\n\t"     // descend, or pop
-                "v_addc_co_u32_e64 %[sp], vcc, 0, %[sp], s[58:59]\n\t"
-                "v_subb_co_u32_e64 %[sp], vcc, %[sp], 0, s[54:55]\n\t"
-                "s_sub_u32 s60, s60, 1\n\t"
-                "v_cmp_gt_i32_e64 s[42:43], 0, %[node]\n\t"
-                "s_cmp_eq_u32 s60, 0\n\t"
-                "s_cbranch_scc1 L_repdone%=\n\t"
-                "v_cmp_le_i32_e64 s[50:51], s79, %[sp]\n\t"        // (a push may have filled the LDS part)
-                "s_and_b64 s[50:51], s[50:51], s[42:43]\n\t"
-                "s_cmp_lg_u64 s[50:51], 0\n\t"
-                "s_cbranch_scc1 L_repdone%=\n\t"
-                "s_cmp_lg_u64 s[42:43], 0\n\t"
-                "s_cbranch_scc1 L_rep%=\n\t"
-                "L_repdone%=:\n\t"
-                "s_mov_b64 exec, s[40:41]\n\t"
-                "s_branch L_top%=\n\t"
-                // ---- doors
-                "L_refill%=:\n\t"
-                "s_mov_b32 %[code], 0\n\t"
-                "s_branch L_out%=\n\t"
-                "L_deep%=:\n\t"
-                "s_mov_b32 %[code], 1\n\t"
-                "s_branch L_out%=\n\t"
-                "L_trip%=:\n\t"
-                "s_mov_b32 %[code], 2\n\t"
-                "s_branch L_out%=\n\t"
-                "L_leafcpp%=:\n\t"
-                "s_mov_b32 %[code], 3\n\t"
-                "s_branch L_out%=\n\t"
-                // ---- leaf step (Kernels.h:200-205 + 36-115): one pair of every lane that waits at a leaf.  The instruction
-                // sequence is hipcc's for the branch-free form of pairIntersectData (same operations, same order, same rounding).
-                "L_leaf%=:\n\t"
-                "s_bitcmp1_b32 s81, 18\n\t"
-                "s_cbranch_scc1 L_leafcpp%=\n\t"
-                // Fused step: when inner lanes exist as well, their node records are requested FIRST (cooperative LDS-DMA: the data
-                // waits in the stage, no registers), then the leaf lanes' pairs; both fetches are in flight together, the leaf
-                // body runs, then the inner lanes read their records back and take one inner step.  One memory round trip
-                // instead of two for the iteration.
-                "s_mov_b32 s67, 0\n\t"
-                "s_cmp_eq_u32 s46, 0\n\t"
-                "s_cbranch_scc1 L_leafbody%=\n\t"
-                "s_bitcmp1_b32 s81, 19\n\t"
-                "s_cbranch_scc1 L_leafbody%=\n\t"
-                "s_mov_b32 s67, 1\n\t"
-                "v_lshlrev_b32_e32 v64, 2, %[node]\n\t"
-                "s_mov_b32 m0, %[stage]\n\t"
-                "s_nop 0\n\t"
-                "v_or_b32_dpp v65, v64, v90 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_or_b32_dpp v66, v64, v90 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_or_b32_dpp v67, v64, v90 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_or_b32_dpp v68, v64, v90 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "buffer_load_dwordx4 v65, %[rsrc], 0 idxen lds\n\t"
-                "s_mov_b32 m0, s75\n\t"
-                "s_nop 0\n\t"
-                "buffer_load_dwordx4 v66, %[rsrc], 0 idxen lds\n\t"
-                "s_mov_b32 m0, s76\n\t"
-                "s_nop 0\n\t"
-                "buffer_load_dwordx4 v67, %[rsrc], 0 idxen lds\n\t"
-                "s_mov_b32 m0, s77\n\t"
-                "s_nop 0\n\t"
-                "buffer_load_dwordx4 v68, %[rsrc], 0 idxen lds\n\t"
-                "L_leafbody%=:\n\t"
-                "s_mov_b64 exec, s[44:45]\n\t"
-                "v_and_b32_e32 v86, s66, %[node]\n\t"                  // current pair
-                "v_lshl_add_u32 v85, %[sp], 10, %[ldscol]\n\t"
-                "v_mul_u32_u24_e32 v87, 48, v86\n\t"
-                "ds_read_b32 v84, v85\n\t"                             // top of the stack: the node after this leaf's last pair
-                "global_load_dwordx4 v[48:51], v87, %[pairs]\n\t"      // e1.xyz e3.x
-                "global_load_dwordx4 v[52:55], v87, %[pairs] offset:16\n\t"   // e2.xyz e3.y
-                "global_load_dwordx4 v[56:59], v87, %[pairs] offset:32\n\t"   // p0.xyz e3.z
-                "s_waitcnt vmcnt(0)\n\t"
-                "v_mul_f32_e64 v60, v50, -v53\n\t"
-                "v_mul_f32_e64 v61, v48, -v54\n\t"
-                "v_mul_f32_e64 v62, v49, -v52\n\t"
-                "v_mul_f32_e64 v63, v59, -v49\n\t"
-                "v_mul_f32_e64 v64, v51, -v50\n\t"
-                "v_mul_f32_e64 v65, v55, -v48\n\t"
-                "v_fmac_f32_e32 v60, v49, v54\n\t"                     // n1 = e1 x e2
-                "v_fmac_f32_e32 v61, v50, v52\n\t"
-                "v_fmac_f32_e32 v62, v48, v53\n\t"
-                "v_fmac_f32_e32 v63, v55, v50\n\t"                     // n2 = e3 x e1
-                "v_fmac_f32_e32 v64, v59, v48\n\t"
-                "v_fmac_f32_e32 v65, v51, v49\n\t"
-                "v_sub_f32_e32 v66, v56, %[ox]\n\t"                    // C = p0 - o
-                "v_sub_f32_e32 v67, v57, %[oy]\n\t"
-                "v_sub_f32_e32 v68, v58, %[oz]\n\t"
-                "v_mul_f32_e64 v69, %[dz], -v67\n\t"
-                "v_mul_f32_e64 v70, %[dx], -v68\n\t"
-                "v_mul_f32_e64 v71, %[dy], -v66\n\t"
-                "v_fmac_f32_e32 v69, %[dy], v68\n\t"                   // R = d x C
-                "v_fmac_f32_e32 v70, %[dz], v66\n\t"
-                "v_fmac_f32_e32 v71, %[dx], v67\n\t"
-                "v_mul_f32_e32 v72, v60, %[dx]\n\t"
-                "v_mul_f32_e32 v73, v63, %[dx]\n\t"
-                "v_mul_f32_e32 v76, v69, v48\n\t"
-                "v_mul_f32_e32 v77, v69, v52\n\t"
-                "v_mul_f32_e32 v80, v69, v51\n\t"
-                "v_mul_f32_e32 v85, v60, v66\n\t"
-                "v_mul_f32_e32 v87, v63, v66\n\t"
-                "v_fmac_f32_e32 v72, v61, %[dy]\n\t"
-                "v_fmac_f32_e32 v73, v64, %[dy]\n\t"
-                "v_fmac_f32_e32 v76, v70, v49\n\t"
-                "v_fmac_f32_e32 v77, v70, v53\n\t"
-                "v_fmac_f32_e32 v80, v70, v55\n\t"
-                "v_fmac_f32_e32 v85, v61, v67\n\t"
-                "v_fmac_f32_e32 v87, v64, v67\n\t"
-                "v_fmac_f32_e32 v72, v62, %[dz]\n\t"                   // det1 = n1 . d
-                "v_fmac_f32_e32 v73, v65, %[dz]\n\t"                   // det2 = n2 . d
-                "v_fmac_f32_e32 v76, v71, v50\n\t"                     // R . e1
-                "v_fmac_f32_e32 v77, v71, v54\n\t"                     // R . e2
-                "v_fmac_f32_e32 v80, v71, v59\n\t"                     // R . e3
-                "v_fmac_f32_e32 v85, v62, v68\n\t"                     // n1 . C
-                "v_fmac_f32_e32 v87, v65, v68\n\t"                     // n2 . C
-                "v_and_b32_e32 v74, 0x80000000, v72\n\t"
-                "v_and_b32_e32 v75, 0x80000000, v73\n\t"
-                "v_xor_b32_e32 v77, v77, v74\n\t"                      // U1
-                "v_xor_b32_e32 v78, v76, v74\n\t"                      // V1
-                "v_xor_b32_e32 v79, v76, v75\n\t"
-                "v_xor_b32_e32 v80, v80, v75\n\t"
-                "v_xor_b32_e32 v85, v85, v74\n\t"                      // T1
-                "v_xor_b32_e32 v87, v87, v75\n\t"                      // T2
-                "v_xor_b32_e32 v79, 0x80000000, v79\n\t"               // U2 = -(R . e1) ^ sgn2
-                "v_xor_b32_e32 v80, 0x80000000, v80\n\t"               // V2 = -(R . e3) ^ sgn2
-                "v_or_b32_e32 v81, v77, v78\n\t"
-                "v_sub_f32_e64 v83, |v72|, v77\n\t"
-                "v_mul_f32_e64 v61, |v72|, %[tnear]\n\t"
-                "v_mul_f32_e64 v62, |v72|, %[tfar]\n\t"
-                "v_mul_f32_e64 v63, |v73|, %[tnear]\n\t"
-                "v_mul_f32_e64 v64, |v73|, %[tfar]\n\t"
-                "v_or_b32_e32 v82, v79, v80\n\t"
-                "v_sub_f32_e64 v60, |v73|, v79\n\t"
-                "v_sub_f32_e32 v83, v83, v78\n\t"                      // W1
-                "v_sub_f32_e32 v60, v60, v80\n\t"                      // W2
-                "v_mul_f32_e64 v65, v85, |v73|\n\t"
-                "v_mul_f32_e64 v66, v87, |v72|\n\t"
-                "v_cmp_gt_i32_e64 s[52:53], 0, v81\n\t"
-                "v_cmp_le_f32_e64 s[56:57], v85, v61\n\t"
-                "v_cmp_gt_f32_e64 s[58:59], v85, v62\n\t"
-                "v_cmp_lt_f32_e64 s[54:55], v83, 0\n\t"
-                "s_or_b64 s[52:53], s[52:53], s[56:57]\n\t"
-                "s_or_b64 s[52:53], s[52:53], s[58:59]\n\t"
-                "s_or_b64 s[52:53], s[52:53], s[54:55]\n\t"            // outside the first triangle
-                "v_cmp_gt_i32_e64 s[54:55], 0, v82\n\t"
-                "v_cmp_le_f32_e64 s[56:57], v87, v63\n\t"
-                "v_cmp_gt_f32_e64 s[58:59], v87, v64\n\t"
-                "v_cmp_lt_f32_e64 s[50:51], v60, 0\n\t"
-                "s_or_b64 s[54:55], s[54:55], s[56:57]\n\t"
-                "s_or_b64 s[54:55], s[54:55], s[58:59]\n\t"
-                "s_or_b64 s[54:55], s[54:55], s[50:51]\n\t"            // outside the second triangle
-                "v_cmp_gt_f32_e64 s[56:57], v65, v66\n\t"              // T1 * |det2| > T2 * |det1|: the second one is nearer
-                "s_and_b64 s[58:59], s[52:53], s[54:55]\n\t"
-                "s_or_b64 s[56:57], s[56:57], s[52:53]\n\t"
-                "s_andn2_b64 s[58:59], exec, s[58:59]\n\t"             // lanes with a hit
-                "s_andn2_b64 s[56:57], s[56:57], s[54:55]\n\t"         // ... in the second triangle
-                "v_cndmask_b32_e64 v67, |v72|, |v73|, s[56:57]\n\t"
-                "v_cndmask_b32_e64 v68, v85, v87, s[56:57]\n\t"
-                "v_cndmask_b32_e64 v69, v77, v79, s[56:57]\n\t"
-                "v_cndmask_b32_e64 v70, v78, v80, s[56:57]\n\t"
-                "v_div_scale_f32 v71, s[50:51], v67, v67, 1.0\n\t"     // 1 / |det|, correctly rounded (hipcc's expansion)
-                "v_rcp_f32_e32 v60, v71\n\t"
-                "v_cndmask_b32_e64 v61, 0, 1, s[56:57]\n\t"
-                "v_lshl_or_b32 v61, v86, 1, v61\n\t"                   // pair * 2 + which
-                "v_fma_f32 v62, -v71, v60, 1.0\n\t"
-                "v_fmac_f32_e32 v60, v62, v60\n\t"
-                "v_div_scale_f32 v62, vcc, 1.0, v67, 1.0\n\t"
-                "v_mul_f32_e32 v63, v62, v60\n\t"
-                "v_fma_f32 v64, -v71, v63, v62\n\t"
-                "v_fmac_f32_e32 v63, v64, v60\n\t"
-                "v_fma_f32 v71, -v71, v63, v62\n\t"
-                "v_div_fmas_f32 v71, v71, v60, v63\n\t"
-                "v_div_fixup_f32 v67, v71, v67, 1.0\n\t"
-                "s_mov_b32 s49, 0x2000000\n\t"
-                "v_mul_f32_e32 v68, v68, v67\n\t"                      // t
-                "v_mul_f32_e32 v69, v69, v67\n\t"                      // u
-                "v_mul_f32_e32 v70, v70, v67\n\t"                      // v
-                "v_cmp_le_u32_e64 s[52:53], s49, %[node]\n\t"          // more pairs in this leaf
-                "v_cndmask_b32_e64 %[tfar], %[tfar], v68, s[58:59]\n\t"
-                "v_cndmask_b32_e64 %[hu], %[hu], v69, s[58:59]\n\t"
-                "v_cndmask_b32_e64 %[hv], %[hv], v70, s[58:59]\n\t"
-                "v_cndmask_b32_e64 %[hidx], %[hidx], v61, s[58:59]\n\t"
-                "v_add_u32_e32 v62, 0xff000001, %[node]\n\t"           // (count - 1, first + 1)
-                "s_andn2_b64 s[54:55], exec, s[52:53]\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "v_cndmask_b32_e64 %[node], v84, v62, s[52:53]\n\t"    // next pair, or pop
-                "v_subb_co_u32_e64 %[sp], vcc, %[sp], 0, s[54:55]\n\t"
-                "s_cmp_lg_u32 s67, 0\n\t"
-                "s_cbranch_scc0 L_leafend%=\n\t"
-                "s_mov_b64 exec, s[42:43]\n\t"                         // fused: the inner lanes' records are in the stage (the leaf body waited vmcnt(0))
-                "s_mov_b32 s60, 1\n\t"                                 // one inner step
-                "v_lshl_add_u32 v63, %[sp], 10, %[ldscol]\n\t"
-                "s_branch L_coopread%=\n\t"
-                "L_leafend%=:\n\t"
-                "s_mov_b64 exec, s[40:41]\n\t"
-                "s_mov_b32 s63, 1\n\t"                                 // a thin wave now runs its inner lanes too
-                "s_branch L_top%=\n\t"
-                "L_out%=:\n\t"
-                "s_mov_b64 exec, s[40:41]\n\t"
-                : [node] "+v"(node), [sp] "+v"(sp), [tfar] "+v"(tFar), [hidx] "+v"(hitIndex), [hu] "+v"(hitU), [hv] "+v"(hitV), [code] "=s"(code), [iter] "+s"(iter)
-                : [tnear] "v"(tNear), [ox] "v"(ox), [oy] "v"(oy), [oz] "v"(oz), [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz),
-                  [vix] "v"(vix), [viy] "v"(viy), [viz] "v"(viz), [vex] "v"(vex), [vey] "v"(vey), [vez] "v"(vez),
-                  [ldscol] "v"(ldsCol), [nodes] "s"(a.nodes), [pairs] "s"(a.pairs), [rsrc] "s"(nodeRsrc), [stage] "s"(stageAddr),
-                  [polA] "s"(polA), [polB] "s"(polB)
-                : "memory", "vcc", "scc",
-                  "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59",
-                  "s60", "s61", "s62", "s63", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s79", "s80", "s81", "s82", "s83",
-                  "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
-                  "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
-                  "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90");
-            afterLeaf = 0;
-            if (code == 0u) break;                                   // REFILL
-            if (code == 2u) { tripped = true; break; }               // TRIP
-            if (code == 3u) {                                        // LEAF (stacks are shallow: the header checked)
-                if (STATS) { cyTop = __builtin_readcyclecounter(); ++stLeaf; stLeafLanes += uint32_t(__popcll(__ballot(int(node) >= int(kLeafBase)))); }
-                RACC_LEAF_STEP(false);
-                if (STATS) cyLeaf += __builtin_readcyclecounter() - cyTop;
-                afterLeaf = 1;
-                continue;
-            }
-            // DEEP: one spill-aware iteration — a pair for every leaf lane, then a step for every inner lane
-            if (STATS) { ++stLeaf; stLeafLanes += uint32_t(__popcll(__ballot(int(node) >= int(kLeafBase)))); }
-            RACC_LEAF_STEP(true);
-            if (int(node) < 0) {
-                const float4* np = a.nodes + size_t(node & 0x7FFFFFFFu) * 4;
-                const uint2 k2 = *reinterpret_cast<const uint2*>(np);
-                const float4 d1 = np[1], d2 = np[2], d3 = np[3];
-                uint32_t popped;
-                RACC_TOP(true, popped);
-                const float tRay = tFar;
-                float tFirst, tLast;
-                slabPairV(d1, d2, d3, vix, viy, viz, vex, vey, vez, tNear, tRay, tFirst, tLast);
-                const float firstDiff = tRay - tFirst, lastDiff = tRay - tLast;
-                const bool any = firstDiff + lastDiff != 0.0f;             // Kernels.h:192
-                const bool lastNearer = tLast < tFirst;                    // signbit(tLast - tFirst), Kernels.h:193
-                const bool both = any & (tFirst != tRay) & (tLast != tRay);   // fmax(tFirst, tLast) != tRay, Kernels.h:194
-                const uint32_t farKid = lastNearer ? k2.x : k2.y;
-                RACC_ABOVE(true, farKid, both);
-                node = any ? (lastNearer ? k2.y : k2.x) : popped;
-                sp = sp + (both ? 1u : 0u) - (any ? 0u : 1u);
-            }
-        }
-        if (tripped) {
-            if (lane == 0) __hip_atomic_fetch_add(a.trips, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
-        }
-    }
-#undef RACC_TOP
-#undef RACC_ABOVE
-#undef RACC_LEAF_STEP
-
-    if (STATS && lane == 0) {
-        atomicAdd(a.stats + 0, (unsigned long long)stInner); atomicAdd(a.stats + 1, (unsigned long long)stInnerLanes);
-        atomicAdd(a.stats + 2, (unsigned long long)stLeaf);  atomicAdd(a.stats + 3, (unsigned long long)stLeafLanes);
-        atomicAdd(a.stats + 4, (unsigned long long)stRefill); atomicAdd(a.stats + 5, (unsigned long long)stLoaded);
-        atomicAdd(a.stats + 6, (unsigned long long)stDeq);   atomicAdd(a.stats + 7, 1ull);
-        atomicAdd(a.stats + 8, cyInner); atomicAdd(a.stats + 10, cyLeaf); atomicAdd(a.stats + 12, cyRefill);
-        atomicAdd(a.stats + 13, (unsigned long long)(__builtin_readcyclecounter() - cyStart));
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t prev = atomicInc(a.cursor + 1, gridDim.x - 1);
-        if (prev == gridDim.x - 1) atomicExch(a.cursor, 0u);
-    }
-}
+#include "racc_kernel_v8.inc"
 
 #ifdef RACC_EXPERIMENTAL
 #include "racc_kernels_experimental.inc"      // V1..V7: earlier generations and ablations, `make EXPERIMENTAL=1`

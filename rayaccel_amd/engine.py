@@ -106,7 +106,7 @@ _lib = None
 
 def build_library(force=False):
     """Compile libracc_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("racc_hip.hip", "racc_device.inc", "racc_kernels_experimental.inc", "scene_build.cpp", "racc_api.cpp", "pathtracer.cpp", "pt_device.hip", "pt_shade.h",
+    srcs = [os.path.join(CSRC, f) for f in ("racc_hip.hip", "racc_device.inc", "racc_kernel_v8.inc", "racc_kernels_experimental.inc", "scene_build.cpp", "racc_api.cpp", "pathtracer.cpp", "pt_device.hip", "pt_shade.h",
                                                  "pt_scene.h", "Makefile")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("racc_hip.h", "RayAccelerator.h")]
     srcs.append(os.path.join(_HERE, "..", "tests", "cpp", "render_check.cpp"))

@@ -53,7 +53,7 @@ for d in sorted(filter(None, (newest(os.path.join(p, "*", "*_counter_collection.
         vals = [x[1] for x in v]
         out[k] = dict(mean_timed_diffuse=float(np.mean(vals[4:24])), launches=len(vals))
 h = hashlib.sha256()
-for rel in ("rayaccel_amd/csrc/racc_hip.hip", "rayaccel_amd/csrc/racc_device.inc"):
+for rel in ("rayaccel_amd/csrc/racc_kernel_v8.inc", "rayaccel_amd/csrc/racc_device.inc"):
     h.update(open(os.path.join(ROOT, rel), "rb").read())
 out["kernel_source_sha256"] = h.hexdigest()
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
