@@ -22,12 +22,14 @@
 #include "pt_scene.h"
 #include "pt_shade.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 extern "C" {
@@ -61,6 +63,8 @@ static_assert(sizeof(ptshade::RayRec) == sizeof(racc::Ray) && sizeof(ptshade::Hi
 struct Renderer {
     const ptscene::Scene* scene = nullptr;
     ptshade::SceneView view{};
+    std::vector<ptshade::ShadeTri> tris;   // one aligned 64 B shading record per triangle (the device consumer's layout): a hit
+                                           // costs ONE cache miss instead of indices -> 3 vertices + 3 normals + material
     uint32_t width = 0, height = 0, tilesX = 0, tilesY = 0, maxDepth = 0;
     uint32_t sampleFirst = 0, sampleCount = 0;
     std::atomic<uint32_t> nextJob{0};      // job = sample * tiles + tile
@@ -109,7 +113,14 @@ struct Renderer {
                 continue;
             }
             const uint32_t sample = r->sampleOf(in->index, i);
-            if (!ptshade::shadeHit(r->view, r->scene->mat, r->maxDepth, ray, hit, lp, sample, reinterpret_cast<ptshade::RayRec&>(out->rays[out->count]), lout[out->count])) continue;
+            if ((lp.pixelDepth >> 24) >= r->maxDepth || hit.triangle >= r->view.triangleCount) continue;        // = shadeHit's guard (PathTracingRenderer.cpp:113-114)
+            if (i + 8 < end) {                // the record of a hit a few rays ahead is on its way while this one is shaded
+                const uint32_t ahead = reinterpret_cast<const ptshade::HitRec&>(in->results[i + 8]).triangle;
+                if (ahead < r->view.triangleCount) __builtin_prefetch(&r->tris[ahead]);
+            }
+            const ptshade::ShadeTri& st = r->tris[hit.triangle];
+            if (!ptshade::shadeSurface(r->scene->mat, ray, hit, lp, sample, st.n0, st.n1, st.n2, ptshade::Vec{st.ng[0], st.ng[1], st.ng[2]}, st.material,
+                                       reinterpret_cast<ptshade::RayRec&>(out->rays[out->count]), lout[out->count])) continue;
             r->sampleOf(out->index, out->count) = sample;
             ++out->count;
         }
@@ -139,6 +150,14 @@ extern "C" int racc_pt_render_file(const char* scene_bin, int device, uint32_t w
     Renderer r;
     r.scene = &sc;
     r.view = ptshade::SceneView{sc.indices.data(), sc.triangleMaterials.data(), sc.normals.data(), sc.vertices.data(), T};
+    r.tris.resize(T);
+    {
+        const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t)
+            pool.emplace_back([&r, T, nt, t] { for (uint32_t k = uint32_t(uint64_t(T) * t / nt); k < uint32_t(uint64_t(T) * (t + 1) / nt); ++k) ptshade::buildShadeTri(r.view, k, r.tris[k]); });
+        for (std::thread& th : pool) th.join();
+    }
     r.width = width; r.height = height; r.tilesX = width / 128; r.tilesY = height / 128;
     r.maxDepth = max_depth ? max_depth : hdr.maxDepth;
     r.sampleFirst = spp_first; r.sampleCount = spp_count;
