@@ -183,6 +183,27 @@ int racc_hip_stream_create(racc_hip_ctx* ctx, void** stream);
 int racc_hip_stream_synchronize(racc_hip_ctx* ctx, void* stream);      /* also reports a watchdog trip */
 int racc_hip_stream_destroy(racc_hip_ctx* ctx, void* stream);
 
+/* ---- multi-GPU: device groups ----------------------------------------------------------------------
+ * ≙ nothing in the reference (its cl_context drives devices[0], RayAccelerator.cpp:467-478).  A group is one engine context per
+ * entry of `devices` (entries may repeat an ordinal: rehearsal on one GPU); the scene and the environment are replicated on
+ * every member (read-only data, Scene.cpp:342-346); racc_hip_group_intersect cuts a host batch into contiguous shards of whole
+ * 64-ray chunks, traces them concurrently (one host thread and one PCIe link per GPU) and lands the results in place, in order.
+ * No exchange between GPUs.  racc_hip_group_ctx gives the members for everything else (lanes, device-resident batches). */
+typedef struct racc_hip_group racc_hip_group;
+typedef struct racc_hip_group_scene racc_hip_group_scene;
+typedef struct racc_hip_group_env racc_hip_group_env;
+int racc_hip_group_create(const int* devices, uint32_t n, const racc_hip_options* opts, racc_hip_group** out);
+int racc_hip_group_destroy(racc_hip_group* group);
+uint32_t racc_hip_group_size(const racc_hip_group* group);
+racc_hip_ctx* racc_hip_group_ctx(racc_hip_group* group, uint32_t i);
+int racc_hip_group_scene_upload(racc_hip_group* group, const void* nodes64, uint32_t node_count, const void* pairs48, uint32_t pair_count,
+                                const uint32_t* remap, uint32_t remap_count, racc_hip_group_scene** out);
+int racc_hip_group_scene_free(racc_hip_group* group, racc_hip_group_scene* scene);
+int racc_hip_group_env_upload(racc_hip_group* group, const float* rgba, uint32_t width, uint32_t height, racc_hip_group_env** out);
+int racc_hip_group_env_free(racc_hip_group* group, racc_hip_group_env* env);
+int racc_hip_group_intersect(racc_hip_group* group, const racc_hip_group_scene* scene, const racc_hip_group_env* env,
+                             const void* rays, void* results, uint32_t count);
+
 /* ---- multi-GPU: hit-record exchange over RCCL/xGMI ------------------------------------------------
  * The path shards without any exchange: rays never interact, the scene is read-only (Scene.cpp:342-346), so every GPU
  * traces its contiguous shard of a batch (one process per GPU, or one racc::Context over several GPUs).  Only a GPU-side

@@ -35,6 +35,8 @@
 #include <cstring>
 #include <new>
 #include <queue>
+#include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -1057,6 +1059,110 @@ int racc_hip_comm_destroy(racc_hip_comm* comm) {
     delete comm;
     return RACC_HIP_OK;
 }
+
+// ---- device groups: the GPUs of one node behind one handle --------------------------------------------------------------
+// The path shards with no exchange (rays never interact, the scene is read-only, Scene.cpp:342-346): a group is n engine
+// contexts, the scene and environment replicated on each, a batch cut into n contiguous shards (multiples of 64 rays, one
+// wave's chunk) traced concurrently, results in place.  Entries of `devices` may repeat an ordinal (rehearsal on one GPU).
+struct racc_hip_group { std::vector<racc_hip_ctx*> ctx; };
+struct racc_hip_group_scene { std::vector<racc_hip_scene*> scene; };
+struct racc_hip_group_env { std::vector<racc_hip_env*> env; };
+
+int racc_hip_group_create(const int* devices, uint32_t n, const racc_hip_options* opts, racc_hip_group** out) {
+    if (!devices || !n || n > 64u || !out) return fail(RACC_HIP_ERR_INVALID, "group_create: bad argument");
+    *out = nullptr;
+    racc_hip_group* g = new (std::nothrow) racc_hip_group();
+    if (!g) return fail(RACC_HIP_ERR_NOMEM, "out of host memory");
+    for (uint32_t i = 0; i < n; ++i) {
+        racc_hip_ctx* c = nullptr;
+        if (int rc = racc_hip_create(devices[i], opts, &c)) { racc_hip_group_destroy(g); return rc; }
+        g->ctx.push_back(c);
+    }
+    *out = g;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_group_destroy(racc_hip_group* g) {
+    if (!g) return RACC_HIP_OK;
+    for (racc_hip_ctx* c : g->ctx) racc_hip_destroy(c);
+    delete g;
+    return RACC_HIP_OK;
+}
+
+uint32_t racc_hip_group_size(const racc_hip_group* g) { return g ? uint32_t(g->ctx.size()) : 0u; }
+
+racc_hip_ctx* racc_hip_group_ctx(racc_hip_group* g, uint32_t i) { return g && i < g->ctx.size() ? g->ctx[i] : nullptr; }
+
+int racc_hip_group_scene_upload(racc_hip_group* g, const void* nodes64, uint32_t node_count, const void* pairs48, uint32_t pair_count,
+                                const uint32_t* remap, uint32_t remap_count, racc_hip_group_scene** out) {
+    if (!g || !out) return fail(RACC_HIP_ERR_INVALID, "group/out is NULL");
+    *out = nullptr;
+    racc_hip_group_scene* s = new (std::nothrow) racc_hip_group_scene();
+    if (!s) return fail(RACC_HIP_ERR_NOMEM, "out of host memory");
+    for (racc_hip_ctx* c : g->ctx) {
+        racc_hip_scene* one = nullptr;
+        if (int rc = racc_hip_scene_upload(c, nodes64, node_count, pairs48, pair_count, remap, remap_count, &one)) { racc_hip_group_scene_free(g, s); return rc; }
+        s->scene.push_back(one);
+    }
+    *out = s;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_group_scene_free(racc_hip_group* g, racc_hip_group_scene* s) {
+    if (!s) return RACC_HIP_OK;
+    for (size_t i = 0; i < s->scene.size(); ++i) racc_hip_scene_free(g && i < g->ctx.size() ? g->ctx[i] : nullptr, s->scene[i]);
+    delete s;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_group_env_upload(racc_hip_group* g, const float* rgba, uint32_t width, uint32_t height, racc_hip_group_env** out) {
+    if (!g || !out) return fail(RACC_HIP_ERR_INVALID, "group/out is NULL");
+    *out = nullptr;
+    racc_hip_group_env* e = new (std::nothrow) racc_hip_group_env();
+    if (!e) return fail(RACC_HIP_ERR_NOMEM, "out of host memory");
+    for (racc_hip_ctx* c : g->ctx) {
+        racc_hip_env* one = nullptr;
+        if (int rc = racc_hip_env_upload(c, rgba, width, height, &one)) { racc_hip_group_env_free(g, e); return rc; }
+        e->env.push_back(one);
+    }
+    *out = e;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_group_env_free(racc_hip_group* g, racc_hip_group_env* e) {
+    if (!e) return RACC_HIP_OK;
+    for (size_t i = 0; i < e->env.size(); ++i) racc_hip_env_free(g && i < g->ctx.size() ? g->ctx[i] : nullptr, e->env[i]);
+    delete e;
+    return RACC_HIP_OK;
+}
+
+int racc_hip_group_intersect(racc_hip_group* g, const racc_hip_group_scene* scene, const racc_hip_group_env* env,
+                             const void* rays, void* results, uint32_t count) {
+    if (!g || !scene || scene->scene.size() != g->ctx.size() || (env && env->env.size() != g->ctx.size()))
+        return fail(RACC_HIP_ERR_INVALID, "group_intersect: the scene/environment does not belong to this group");
+    if (!count) return RACC_HIP_OK;
+    if (!rays || !results) return fail(RACC_HIP_ERR_INVALID, "rays/results is NULL");
+    const uint32_t n = uint32_t(g->ctx.size());
+    const uint32_t per = ((count + n - 1u) / n + 63u) / 64u * 64u;        // contiguous shards, whole chunks of 64 rays
+    std::vector<int> rc(n, RACC_HIP_OK);
+    std::vector<std::string> msg(n);
+    std::vector<std::thread> workers;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t b = uint64_t(i) * per;
+        if (b >= count) break;
+        const uint32_t cnt = uint32_t(uint64_t(count) - b < per ? uint64_t(count) - b : per);
+        workers.emplace_back([=, &rc, &msg] {     // one host thread per GPU: the blocking entry copies in, traces, copies out
+            rc[i] = racc_hip_intersect(g->ctx[i], scene->scene[i], env ? env->env[i] : nullptr, static_cast<const char*>(rays) + b * 32,
+                                       static_cast<char*>(results) + b * 16, cnt, 0);
+            if (rc[i] != RACC_HIP_OK) msg[i] = racc_hip_last_error();
+        });
+    }
+    for (std::thread& t : workers) t.join();
+    for (uint32_t i = 0; i < n; ++i)
+        if (rc[i] != RACC_HIP_OK) return fail(rc[i], msg[i].c_str());
+    return RACC_HIP_OK;
+}
+
 
 int racc_hip_synchronize(racc_hip_ctx* ctx) {
     if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");

@@ -91,6 +91,15 @@ ABI = {
     "racc_hip_stream_create": (_i, [_vp, _P(_vp)]),
     "racc_hip_stream_synchronize": (_i, [_vp, _vp]),
     "racc_hip_stream_destroy": (_i, [_vp, _vp]),
+    "racc_hip_group_create": (_i, [_P(_i), _u32, _P(Options), _P(_vp)]),
+    "racc_hip_group_destroy": (_i, [_vp]),
+    "racc_hip_group_size": (_u32, [_vp]),
+    "racc_hip_group_ctx": (_vp, [_vp, _u32]),
+    "racc_hip_group_scene_upload": (_i, [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _P(_vp)]),
+    "racc_hip_group_scene_free": (_i, [_vp, _vp]),
+    "racc_hip_group_env_upload": (_i, [_vp, _vp, _u32, _u32, _P(_vp)]),
+    "racc_hip_group_env_free": (_i, [_vp, _vp]),
+    "racc_hip_group_intersect": (_i, [_vp, _vp, _vp, _vp, _vp, _u32]),
     "racc_hip_comm_unique_id": (_i, [_vp]),
     "racc_hip_comm_init_rank": (_i, [_vp, _vp, _i, _i, _P(_vp)]),
     "racc_hip_allgather_results": (_i, [_vp, _vp, _vp, _u32, _vp]),
@@ -372,6 +381,46 @@ class Context:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+
+class Group:
+    """The GPUs of one node behind one handle (racc_hip_group_*): scene replicated, host batches sharded, no exchange."""
+
+    def __init__(self, devices):
+        lib = load_library()
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(lib.racc_hip_group_create(arr, len(devices), None, C.byref(h)))
+        self._h, self.size = h, lib.racc_hip_group_size(h)
+        self._scene = self._env = None
+
+    def upload(self, nodes, pairs, remap, env_rgba=None):
+        lib = load_library()
+        nodes, pairs, remap = np.ascontiguousarray(nodes), np.ascontiguousarray(pairs), np.ascontiguousarray(remap, np.uint32)
+        s = C.c_void_p()
+        _check(lib.racc_hip_group_scene_upload(self._h, _ptr(nodes), len(nodes), _ptr(pairs), len(pairs), _ptr(remap), len(remap), C.byref(s)))
+        self._scene = s
+        if env_rgba is not None:
+            img = np.ascontiguousarray(env_rgba, np.float32)
+            e = C.c_void_p()
+            _check(lib.racc_hip_group_env_upload(self._h, _ptr(img), img.shape[1], img.shape[0], C.byref(e)))
+            self._env = e
+
+    def intersect(self, rays):
+        rays = np.ascontiguousarray(rays)
+        out = np.zeros(len(rays), RESULT_DTYPE)
+        _check(load_library().racc_hip_group_intersect(self._h, self._scene, self._env, _ptr(rays), _ptr(out), len(rays)))
+        return out
+
+    def destroy(self):
+        lib = load_library()
+        if self._scene:
+            lib.racc_hip_group_scene_free(self._h, self._scene)
+        if self._env:
+            lib.racc_hip_group_env_free(self._h, self._env)
+        if self._h:
+            lib.racc_hip_group_destroy(self._h)
+        self._h = self._scene = self._env = None
 
 
 class Comm:

@@ -423,3 +423,18 @@ def test_api_misuse_is_reported_not_fatal(gpu_ctx, small):
         gpu_ctx.intersect_device(small["scene"], small["env"], 1, 1, 64, lane=17)                 # lane out of range
     rays = small["primary"][:1000]
     assert_bit_exact(gpu_ctx.intersect(small["scene"], small["env"], rays), orc.traverse(small["blobs"], rays, env=small["sc"]["env"]), "after the misuse")
+
+
+def test_device_group_shards_a_host_batch(full):
+    """Multi-device behind the C-ABI (racc_hip_group_*), rehearsed with the entry list [0, 0, 0] on the one GPU of the box: three
+    engine contexts, the scene replicated, a ragged 1,000,003-ray batch cut into contiguous shards of whole 64-ray chunks and
+    traced concurrently from three host threads.  Bit-exact, in place, in order."""
+    rays = np.ascontiguousarray(np.concatenate([full["primary"][:1000000], full["primary"][:3]]))
+    grp = ra.Group([0, 0, 0])
+    try:
+        assert grp.size == 3
+        grp.upload(full["host"].nodes, full["host"].pairs, full["host"].remap, full["sc"]["env"])
+        got = grp.intersect(rays)
+    finally:
+        grp.destroy()
+    assert_bit_exact(got, orc.traverse(full["blobs"], rays, env=full["sc"]["env"], threads=8), "device group")
