@@ -301,6 +301,7 @@ const Variant kVariants[] = {
     {256, 10, 0, traverseKernelV8<256, 9, false>, false, true, 1, 2, 4 * 1040},           // 41: V8 with an 8-entry LDS stack (exercises the DEEP door and the spill: 2.6 % of the bench rays)
     {256, 14, 0, traverseKernelV8<256, 13, true>, false, true, 1, 2, 4 * 1040},           // 42: variant 43 + statistics (debug; only the C++ parts count: refills, rays loaded, waves)
     {256, 14, 0, traverseKernelV8<256, 13, false>, false, true, 1, 2, 4 * 1040},          // 43: V8, 12-entry LDS stack: the default
+    {256, 14, 0, traverseKernelV8<256, 13, false, false>, false, false, 1, 2, 4 * 1040},  // 44: variant 43 with the probe-image lookup in its own epilogue (no envShadeKernel launch)
 };
 constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kSoaVariant = 27;
