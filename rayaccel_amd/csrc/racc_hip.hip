@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <queue>
 #include <string>
@@ -49,6 +50,8 @@ namespace {
 #include "racc_device.inc"
 
 #include "racc_kernel_v8.inc"
+
+#include "racc_kernel_v9.inc"
 
 #ifdef RACC_EXPERIMENTAL
 #include "racc_kernels_experimental.inc"      // V1..V7: earlier generations and ablations, `make EXPERIMENTAL=1`
@@ -126,6 +129,9 @@ struct racc_hip_ctx {
 
 struct racc_hip_scene {
     float4* nodes = nullptr;
+    float4* nodesWide = nullptr;    // the same tree collapsed into 4-wide 128 B records (collapseWide)
+    uint32_t wideCount = 0;
+    uint32_t wideStack = 0;         // upper bound of a ray's stack entries in the wide tree
     float4* nodesSoa = nullptr;     // only when the context asks for the SoA ablation variant
     float4* pairs = nullptr;
     uint32_t* remap = nullptr;
@@ -223,6 +229,68 @@ void reorderNodes(const GpuNodeHost* in, uint32_t n, std::vector<GpuNodeHost>& o
     }
 }
 
+// 4-wide device format (racc_kernel_v9.inc).  The two children of a BVH2 node are the first candidates; the inner candidate
+// with the largest surface area is replaced, in place (spatial neighbours stay neighbours), by its own two children until
+// there are four or only leaves are left.  Boxes are copied, never recomputed: every box a ray is tested against is one
+// the reference tests it against.  Nodes are numbered breadth first.  An unused slot holds a box at +inf (never entered:
+// its entry distance is +inf or its exit distance -inf) and the ref of a real leaf, so that even a ray whose arithmetic
+// has gone non-finite can only be sent to geometry that exists.
+struct WideNode { uint32_t ref[4]; float plane[6][4]; uint32_t pad[4]; };      // planes: lo.x hi.x lo.y hi.y lo.z hi.z, four children each
+static_assert(sizeof(WideNode) == 128, "one L1 line");
+
+void collapseWide(const GpuNodeHost* in, uint32_t n, std::vector<WideNode>& out, uint32_t& stackBound) {
+    struct Cand { uint32_t ref; float mn[3], mx[3]; };
+    auto area = [](const Cand& c) {
+        const double x = double(c.mx[0]) - c.mn[0], y = double(c.mx[1]) - c.mn[1], z = double(c.mx[2]) - c.mn[2];
+        return x * y + x * z + y * z;
+    };
+    std::vector<uint32_t> map(n, 0xFFFFFFFFu), queue, depth;      // BVH2 index -> wide index; BFS queue of BVH2 indices; depth of each wide node
+    queue.reserve(n); depth.reserve(n); out.clear(); out.reserve(n / 2 + 1);
+    queue.push_back(0); depth.push_back(1); map[0] = 0;
+    uint32_t height = 0;
+    const uint32_t firstLeaf = (in[0].first & 0x80000000u) ? 0x01000000u : in[0].first;      // a real leaf: pair 0 always exists (validated)
+    for (size_t qh = 0; qh < queue.size(); ++qh) {
+        const GpuNodeHost& g = in[queue[qh]];
+        height = depth[qh] > height ? depth[qh] : height;
+        Cand c[4]; int k = 2;
+        c[0].ref = g.first; std::memcpy(c[0].mn, g.box + 0, 12); std::memcpy(c[0].mx, g.box + 3, 12);
+        c[1].ref = g.last;  std::memcpy(c[1].mn, g.box + 6, 12); std::memcpy(c[1].mx, g.box + 9, 12);
+        while (k < 4) {
+            int best = -1; double bestA = -1.0;
+            for (int i = 0; i < k; ++i)
+                if ((c[i].ref & 0x80000000u) && area(c[i]) > bestA) { bestA = area(c[i]); best = i; }
+            if (best < 0) break;
+            const GpuNodeHost& m = in[c[best].ref & 0x7FFFFFFFu];
+            for (int i = k; i > best + 1; --i) c[i] = c[i - 1];
+            c[best].ref = m.first; std::memcpy(c[best].mn, m.box + 0, 12); std::memcpy(c[best].mx, m.box + 3, 12);
+            c[best + 1].ref = m.last; std::memcpy(c[best + 1].mn, m.box + 6, 12); std::memcpy(c[best + 1].mx, m.box + 9, 12);
+            ++k;
+        }
+        WideNode w{};
+        for (int i = 0; i < 4; ++i) {
+            if (i < k) {
+                uint32_t r = c[i].ref;
+                if (r & 0x80000000u) {
+                    const uint32_t t = r & 0x7FFFFFFFu;
+                    map[t] = uint32_t(queue.size());
+                    queue.push_back(t); depth.push_back(depth[qh] + 1);
+                    r = 0x80000000u | map[t];
+                }
+                w.ref[i] = r;
+                for (int ax = 0; ax < 3; ++ax) {      // the reference's slab test takes min/max of the two plane distances: an inverted box acts as its mirror image
+                    w.plane[2 * ax][i] = c[i].mn[ax] < c[i].mx[ax] ? c[i].mn[ax] : c[i].mx[ax];
+                    w.plane[2 * ax + 1][i] = c[i].mn[ax] < c[i].mx[ax] ? c[i].mx[ax] : c[i].mn[ax];
+                }
+            } else {
+                w.ref[i] = firstLeaf;
+                for (int p = 0; p < 6; ++p) w.plane[p][i] = std::numeric_limits<float>::infinity();
+            }
+        }
+        out.push_back(w);
+    }
+    stackBound = 3u * height + 1u;      // at most three entries per level of the path
+}
+
 int ensureSpill(racc_hip_ctx* ctx, Lane& lane, uint32_t gridThreads, uint32_t levels) {
     const size_t words = size_t(gridThreads) * (levels ? levels : 1u);
     if (lane.spillWords >= words) return RACC_HIP_OK;
@@ -247,6 +315,7 @@ struct Variant {
     int slots = 1;             // ray slots per lane (V4: 2); ldsLevels counts all of them
     int reserved = 0;          // LDS levels the kernel keeps for itself (V5: the sentinel; V6: sentinel + trash level)
     int stagePerWave = 0;      // bytes of LDS-DMA stage per wave (V6 COOP)
+    bool wide = false;         // traverses the 4-wide device format (V9)
     int stackLevels() const { return (ldsLevels > 32 ? ldsLevels - (kRecFields + 1) : ldsLevels / slots) - reserved; }   // V3 rows fold the record words into ldsLevels
 };
 // kernel_variant n selects kVariants[n-1]; 0 selects the default (V8).  LDS per workgroup = cacheNodes*64 + ldsLevels*block*4
@@ -302,6 +371,11 @@ const Variant kVariants[] = {
     {256, 14, 0, traverseKernelV8<256, 13, true>, false, true, 1, 2, 4 * 1040},           // 42: variant 43 + statistics (debug; only the C++ parts count: refills, rays loaded, waves)
     {256, 14, 0, traverseKernelV8<256, 13, false>, false, true, 1, 2, 4 * 1040},          // 43: V8, 12-entry LDS stack: the default
     {256, 14, 0, traverseKernelV8<256, 13, false, false>, false, false, 1, 2, 4 * 1040},  // 44: variant 43 with the probe-image lookup in its own epilogue (no envShadeKernel launch)
+    {256, 19, 0, traverseKernelV9<256, 19, false, true>, false, true, 1, 1, 8 * 1040, true},    // 45: V9 (4-wide nodes, hot loop in assembly), 18-entry LDS stack: 3 workgroups per CU
+    {256, 7, 0, traverseKernelV9<256, 7, false, false>, false, true, 1, 1, 8 * 1040, true},     // 46: V9 in plain C++, 6-entry LDS stack + spill: 4 workgroups per CU (exercises the spill)
+    {256, 19, 0, traverseKernelV9<256, 19, true, false>, false, true, 1, 1, 8 * 1040, true},    // 47: V9 in plain C++ + statistics (debug)
+    {256, 19, 0, traverseKernelV9<256, 19, false, false>, false, true, 1, 1, 8 * 1040, true},   // 48: V9 in plain C++ (A/B of the assembly block)
+    {256, 8, 0, traverseKernelV9<256, 8, false, true>, false, true, 1, 1, 8 * 1040, true},      // 49: variant 45 with a 7-entry LDS stack (exercises the DEEP door and the spill)
 };
 constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kSoaVariant = 27;
@@ -351,7 +425,8 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     const uint32_t blocksNeeded = (count + uint32_t(v.block) - 1) / uint32_t(v.block);
     if (blocks > blocksNeeded) blocks = blocksNeeded;
     const uint32_t gridThreads = blocks * uint32_t(v.block);
-    const uint32_t spillLevels = (scene->info.inner_height > uint32_t(v.stackLevels()) ? scene->info.inner_height - uint32_t(v.stackLevels()) : 0u) * uint32_t(v.slots);
+    const uint32_t stackBound = v.wide ? scene->wideStack : scene->info.inner_height;
+    const uint32_t spillLevels = (stackBound > uint32_t(v.stackLevels()) ? stackBound - uint32_t(v.stackLevels()) : 0u) * uint32_t(v.slots);
     if (int rc = ensureSpill(ctx, lane, uint32_t(ctx->numCUs) * 2048u, spillLevels)) return rc;
 
     TraverseArgs a;
@@ -362,6 +437,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.cacheCount = scene->info.node_count < uint32_t(v.cacheNodes) ? scene->info.node_count : uint32_t(v.cacheNodes);
     a.nodeBytes = scene->info.node_count * 64u;
     a.nodesSoa = scene->nodesSoa; a.nodeCount = scene->info.node_count;
+    if (v.wide) { a.nodes = scene->nodesWide; a.nodeCount = scene->wideCount; a.nodeBytes = scene->wideCount * 128u; }
     if (&v == &kVariants[kSoaVariant - 1] && !scene->nodesSoa) return fail(RACC_HIP_ERR_INVALID, "the SoA ablation variant needs a scene uploaded through a context created with that variant");
     a.pairBytes = scene->info.pair_count * 48u;
     a.env = env ? env->pixels : nullptr;
@@ -600,14 +676,24 @@ int racc_hip_scene_upload(racc_hip_ctx* ctx, const void* nodes64, uint32_t node_
         e = hipMalloc(reinterpret_cast<void**>(&s->nodesSoa), nb);
         if (e == hipSuccess) e = hipMemcpy(s->nodesSoa, planes.data(), nb, hipMemcpyHostToDevice);
     }
+    size_t wb = 0;
+    if (e == hipSuccess) {
+        std::vector<WideNode> wide;
+        collapseWide(static_cast<const GpuNodeHost*>(nodes64), node_count, wide, s->wideStack);
+        s->wideCount = uint32_t(wide.size());
+        wb = wide.size() * sizeof(WideNode);
+        e = hipMalloc(reinterpret_cast<void**>(&s->nodesWide), wb);
+        if (e == hipSuccess) e = hipMemcpy(s->nodesWide, wide.data(), wb, hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMemcpy(s->pairs, pairs48, pb, hipMemcpyHostToDevice);
     if (e == hipSuccess && rb) e = hipMemcpy(s->remap, remap, rb, hipMemcpyHostToDevice);
     if (e != hipSuccess) { racc_hip_scene_free(ctx, s); return fail(RACC_HIP_ERR_DEVICE, "scene upload", e); }
     info.node_count = node_count; info.pair_count = pair_count; info.remap_count = remap_count;
-    info.device_bytes = nb + pb + rb;
+    info.device_bytes = nb + wb + pb + rb;
     {
         const Variant& v = pickVariant(ctx, info.inner_height);
-        info.spill_levels = info.inner_height > uint32_t(v.stackLevels()) ? info.inner_height - uint32_t(v.stackLevels()) : 0u;
+        const uint32_t bound = v.wide ? s->wideStack : info.inner_height;
+        info.spill_levels = bound > uint32_t(v.stackLevels()) ? bound - uint32_t(v.stackLevels()) : 0u;
     }
     s->info = info;
     *out = s;
@@ -618,6 +704,7 @@ int racc_hip_scene_free(racc_hip_ctx* ctx, racc_hip_scene* s) {
     if (!s) return RACC_HIP_OK;
     if (ctx) hipSetDevice(ctx->device);
     if (s->nodes) hipFree(s->nodes);
+    if (s->nodesWide) hipFree(s->nodesWide);
     if (s->nodesSoa) hipFree(s->nodesSoa);
     if (s->pairs) hipFree(s->pairs);
     if (s->remap) hipFree(s->remap);

@@ -1,4 +1,4 @@
-"""Writes the bench scene's blobs and its 1M diffuse batch as raw files for oracle/wave_sim and oracle/split_sim."""
+"""Writes the bench scene's blobs and its 1M diffuse batch as raw files for oracle/wave_sim, oracle/split_sim and oracle/wide_sim."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,6 +14,7 @@ ref = orc.traverse(blobs, prim, threads=8)
 diff = synth.diffuse_bounce_rays(sc, prim, ref, 1 << 20)
 blobs["nodes"].tofile(os.path.join(out, "nodes.bin"))
 blobs["pairs"].tofile(os.path.join(out, "pairs.bin"))
+blobs["remap"].tofile(os.path.join(out, "remap.bin"))
 diff.tofile(os.path.join(out, "diffuse.bin"))
 prim.tofile(os.path.join(out, "primary.bin"))
 print(out, len(blobs["nodes"]), len(blobs["pairs"]), len(diff))
