@@ -401,11 +401,11 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     const uint32_t ldsBytes = uint32_t(v.cacheNodes) * 64u + uint32_t(v.ldsLevels) * uint32_t(v.block) * 4u + (v.ldsLevels > 32 ? 272u : 0u) +
                               uint32_t(v.stagePerWave) * uint32_t(v.block / 64);
     // Persistent grid: as many waves as the LDS allows (5 per SIMD with the default kernel) when the GPU is otherwise idle.
-    // When another lane's launch is still running — a caller issuing batch after batch — a launch takes about half of that:
+    // When another lane's launch is still running — a caller issuing batch after batch — a launch takes 2 per SIMD:
     // two or three launches are then co-resident, each one's drain (its last, longest rays: ~0.13 ms during which most of
     // its waves have nothing left) runs beside the others' bulk instead of leaving the machine empty.  Measured on 1M-ray
     // diffuse batches (tools/gpu_overlap.py): 0.378 ms per batch one at a time; back to back over 3 lanes 0.294 with full
-    // grids, 0.273 with 3 waves per SIMD each.
+    // grids, 0.271 with 3 waves per SIMD each, 0.266 with 2 (0.33 / 0.28 with four / five lanes in rotation: three it is).
     uint32_t wavesPerSimd = ctx->opts.waves_per_simd ? ctx->opts.waves_per_simd : lane.forceWavesPerSimd;
     if (!wavesPerSimd) {
         wavesPerSimd = 6u;
@@ -413,7 +413,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
         //  3.42 Grays/s end to end with full grids, 3.08 with halved ones)
         for (uint32_t i = 0; i < ctx->opts.lanes && count <= (2u << 20); ++i) {
             const Lane& other = ctx->lanes[i];
-            if (&other != &lane && other.everLaunched.load(std::memory_order_relaxed) && hipEventQuery(other.done) == hipErrorNotReady) { wavesPerSimd = 3u; break; }
+            if (&other != &lane && other.everLaunched.load(std::memory_order_relaxed) && hipEventQuery(other.done) == hipErrorNotReady) { wavesPerSimd = 2u; break; }
         }
         (void)hipGetLastError();      // hipErrorNotReady is not an error
     }
@@ -926,7 +926,10 @@ int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, co
                               const void* d_rays, void* d_results, uint32_t count, uint32_t lane, void* stream) {
     if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
     // round robin over (up to) three lanes: consecutive launches overlap; a fourth in flight measured slower (3.35 vs 3.84 Grays/s)
-    if (lane == RACC_HIP_LANE_AUTO) lane = ctx->nextLane.fetch_add(1u) % (ctx->opts.lanes < 3u ? ctx->opts.lanes : 3u);
+    if (lane == RACC_HIP_LANE_AUTO) {
+        static const uint32_t rot = getenv("RACC_AUTO_LANES") ? uint32_t(atoi(getenv("RACC_AUTO_LANES"))) : 3u;
+        lane = ctx->nextLane.fetch_add(1u) % (ctx->opts.lanes < rot ? ctx->opts.lanes : rot);
+    }
     if (int rc = checkLane(ctx, lane)) return rc;
     if (!scene) return fail(RACC_HIP_ERR_INVALID, "scene is NULL");
     if (!count) return RACC_HIP_OK;
