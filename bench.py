@@ -266,6 +266,24 @@ def main():
             slope = (scaling[str(1 << 23)] - scaling[str(1 << 20)]) / 7.0          # ms per 2^20 rays
             extras["batch_scaling"] = {"kernel_ms_by_rays": scaling, "steady_state_mrays_per_s": round((1 << 20) / slope / 1e3, 1),
                                        "fixed_ms": round(scaling[str(1 << 20)] - slope, 4)}
+            # the optional 4-wide kernel (kernel_variant 45) on the same batches: its own context, same scene blobs
+            try:
+                with ra.Context(device=device, kernel_variant=45, time_kernels=0) as wctx:
+                    wscene = wctx.upload_scene(host.nodes, host.pairs, host.remap)
+                    wenv = wctx.create_environment(sc["env"])
+                    wide = {}
+                    for nn in (1 << 16, 1 << 18, 1 << 20, 1 << 22):
+                        wctx.intersect_device_timed(wscene, wenv, d_many.data_ptr(), d_many_out.data_ptr(), nn, 2)
+                        wide[str(nn)] = round(float(np.median(wctx.intersect_device_timed(wscene, wenv, d_many.data_ptr(), d_many_out.data_ptr(), nn, 7))), 4)
+                    wctx.intersect_device(wscene, wenv, d_rays.data_ptr(), outs[-1].data_ptr(), n, lane=0)
+                    wctx.wait(0)
+                    differing = int((outs[-1].view(torch.int32) != d_out.view(torch.int32)).any(dim=1).sum().item())
+                    extras["wide_kernel_variant_45"] = {"kernel_ms_by_rays": wide, "default_kernel_ms_by_rays": {k: scaling[k] for k in wide},
+                                                        "records_differing_from_default_in_1M": differing,
+                                                        "note": "4-wide nodes: same closest hit (exact-distance ties may resolve to the other primitive), shorter dependent chain"}
+                    wscene.destroy(); wenv.destroy()
+            except ra.RaccError as e:
+                extras["wide_kernel_variant_45"] = {"error": str(e)}
             del d_many, d_many_out
 
         # BASELINE configs[4]: the path tracer, 1920x1080, end to end on this GPU.  Device-resident consumer (generation and
