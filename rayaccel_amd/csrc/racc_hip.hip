@@ -447,7 +447,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.spillStride = gridThreads;
     a.chunk = optOr(ctx->opts.chunk, 64u * uint32_t(v.slots));
     if (a.chunk > 65536u) a.chunk = 65536u;      // grid waves x chunk (the statically assigned first chunks) must stay far below 2^32
-    a.refillMin = optOr(ctx->opts.refill_min, 32u);
+    a.refillMin = optOr(ctx->opts.refill_min, 20u);      // tools/gpu_policy_sweep.py: 12-20 idle lanes beat 32 by 2 % (4M-ray launch) to 3 % (1M-ray launches back to back); 44: -15 %
     a.leafMin = optOr(ctx->opts.leaf_min, 12u);
     a.maxIters = ctx->maxIters;
     a.trips = ctx->devTrips;
