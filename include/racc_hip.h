@@ -48,7 +48,7 @@ typedef struct racc_hip_options {
     uint32_t waves_per_simd;   /* persistent-grid occupancy target, 1..8; 0 => engine default */
     uint32_t kernel_variant;   /* 0 => engine default (V8: reference traversal order, results bit-identical to the oracle);
                                   45 => the 4-wide kernel (V9: same closest hit, exact-distance ties may resolve to the other
-                                  primitive; faster on batches below ~200k rays); others: DESIGN.md §3, racc_hip_variant_available */
+                                  primitive; 12-20 % faster on batches below ~200k rays, slower when launches overlap); others: DESIGN.md §3, racc_hip_variant_available */
     uint32_t refill_min;       /* idle lanes that trigger a wave refill; 0 => default */
     uint32_t leaf_min;         /* leaf-holding lanes that trigger a leaf step; 0 => default */
     uint32_t chunk;            /* rays a wave dequeues per cursor atomic; 0 => default */
