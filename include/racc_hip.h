@@ -67,7 +67,10 @@ typedef struct racc_hip_options {
     uint32_t leaf_step;        /* 0/1 => the leaf step runs inside the kernel's assembly block and takes the inner lanes' step along
                                   (one memory round trip for both); 2 => in C++ through the block's LEAF door; 3 => in the block,
                                   not fused (A/B; same results) */
-    uint32_t reserved[1];
+    uint32_t wide_below;       /* launches of fewer rays than this use the 4-wide kernel (kernel_variant 45) instead of the
+                                  context's kernel: a launch of <= ~200k rays is all dependent chain, and the wide tree halves
+                                  it (27k-ray launch, the reference's stream size: 0.10 instead of 0.12 ms).  Results: see
+                                  kernel_variant 45.  0 => never (default) */
 } racc_hip_options;
 
 typedef struct racc_hip_scene_info {

@@ -379,6 +379,7 @@ const Variant kVariants[] = {
 };
 constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kSoaVariant = 27;
+constexpr int kWideVariant = 45;
 constexpr int kDefaultVariant = 43;   // V8, 12-entry LDS stack + global spill (any tree height)
 constexpr int kSpillFallback = kDefaultVariant;    // used when a tree is taller than an LDS-only variant's stack
 constexpr uint32_t kLdsPerCU = 160u * 1024u;
@@ -396,6 +397,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
                    const void* dRays, void* dResults, uint32_t count) {
     if (!count) return RACC_HIP_OK;
     const Variant* vp = &pickVariant(ctx, scene->info.inner_height);
+    if (count < ctx->opts.wide_below && !vp->wide) vp = &kVariants[kWideVariant - 1];      // small launch: the shorter dependent chain wins
     if (vp->noSpill && scene->info.inner_height > uint32_t(vp->stackLevels())) vp = &kVariants[kSpillFallback - 1];   // tall tree
     const Variant& v = *vp;
     const uint32_t ldsBytes = uint32_t(v.cacheNodes) * 64u + uint32_t(v.ldsLevels) * uint32_t(v.block) * 4u + (v.ldsLevels > 32 ? 272u : 0u) +

@@ -147,6 +147,22 @@ def test_wide_kernels_full_size(full):
             d_r.free(); scene.destroy(); env.destroy()
 
 
+def test_wide_below_switches_small_launches(small_scene, small_host, small):
+    """wide_below: launches below the threshold take the 4-wide kernel (seen in the launch's LDS footprint), the others the
+    context's own; both agree with the oracle."""
+    rays = _batches(small)["diffuse"]
+    ref = orc.traverse(small["blobs"], rays, env=small_scene["env"])
+    with ra.Context(device=0, wide_below=20000) as ctx:
+        scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
+        env = ctx.create_environment(small_scene["env"])
+        assert_same_closest_hit(ctx.intersect(scene, env, rays[:19999]), ref[:19999], "below the threshold")
+        wide_lds = ctx.launch_info(0)["lds_bytes_per_block"]
+        assert_bit_exact(ctx.intersect(scene, env, rays), ref, "above the threshold")
+        assert ctx.launch_info(0)["lds_bytes_per_block"] < wide_lds       # 128 B per lane of fetch stage against 64 B
+        assert_same_closest_hit(ctx.intersect(scene, env, rays[:64]), ref[:64], "below again (spill area re-sized)")
+        scene.destroy(); env.destroy()
+
+
 def test_malformed_blobs_are_rejected(gpu_ctx, small_host):
     nodes = small_host.nodes.copy()
     with pytest.raises(ra.RaccError):                      # cycle: node 1 points back to the root
