@@ -25,6 +25,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Deployment setting of the HIP runtime, read when it initialises: hardware queues for the engine's lanes (kernels of two HIP
+# streams that share a hardware queue do not overlap; the default of 4 leaves room for three lanes in rotation, 8 for six).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_MEASURED_GBS = 6290.0      # same guide: float4-copy ceiling
@@ -127,7 +130,7 @@ def main():
     full = args.grid == 700
     sc = synth.battlefield_synth() if full else synth.battlefield_synth(grid=args.grid, boxes=args.grid * 6, quads=args.grid * 28)
     host = ra.HostScene(sc["vertices"], sc["indices"])
-    engine_opts = dict(lanes=4, time_kernels=1)
+    engine_opts = dict(time_kernels=1)
     engine_opts.update(json.loads(args.engine_opts) if args.engine_opts else {})
     ctx = ra.Context(device=device, **engine_opts)
     lanes = ctx.lanes
@@ -415,10 +418,11 @@ def main():
             "higher_is_better": True, "scaling": args.mode, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("battlefield-synth (stand-in; reference scene unavailable), %d triangles, " % len(sc["indices"])) +
-                                   ("1M 1st-bounce diffuse rays per GPU per step (BASELINE configs[2]/[3]), steps issued back to back over %d engine lanes" % lanes
+                                   ("1M 1st-bounce diffuse rays per GPU per step (BASELINE configs[2]/[3]), steps issued back to back over %d engine lanes" % ctx.auto_lanes
                                     if args.mode == "weak" else "ONE 8M-ray 1st-bounce diffuse batch per step cut into %d contiguous shards (BASELINE configs[3])" % world),
                        "rays_per_gpu": n, "scene": sc["name"], "parallelism": "rays sharded x%d, scene replicated" % world,
-                       "grid_blocks": launch["grid_blocks"], "waves_per_simd": launch["waves_per_simd"], "lanes": lanes},
+                       "grid_blocks": launch["grid_blocks"], "waves_per_simd": launch["waves_per_simd"], "lanes": lanes,
+                       "lanes_in_rotation": ctx.auto_lanes, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         line.update(extras)

@@ -43,7 +43,7 @@ typedef struct racc_host_scene racc_host_scene;/* host-side build product (refer
 
 typedef struct racc_hip_options {
     uint32_t struct_size;      /* = sizeof(racc_hip_options) */
-    uint32_t lanes;            /* concurrent submission lanes, each with its own HIP stream
+    uint32_t lanes;            /* concurrent submission lanes, each with its own HIP stream (0 => default, racc_hip_lane_count)
                                   (≙ gpuSubmissionThreads queues, RayAccelerator.cpp:711-717); 0 => 4 */
     uint32_t waves_per_simd;   /* persistent-grid occupancy target, 1..8; 0 => engine default */
     uint32_t kernel_variant;   /* 0 => engine default (V8: reference traversal order, results bit-identical to the oracle);
@@ -93,6 +93,12 @@ typedef struct racc_hip_launch_info {
 
 const char* racc_hip_last_error(void);             /* thread-local, never NULL */
 const char* racc_hip_version(void);
+/* The lanes a context has (options.lanes, or the default: 4; 6 when the HIP runtime was given >= 8 hardware queues,
+ * GPU_MAX_HW_QUEUES) and how many of them RACC_HIP_LANE_AUTO rotates over (3 or 6: kernels of two streams that share a
+ * hardware queue do not overlap; RACC_AUTO_LANES overrides).  A caller that rotates result buffers needs at least
+ * `auto_lanes` of them.  Either pointer may be NULL. */
+int racc_hip_lane_count(const racc_hip_ctx* ctx, uint32_t* lanes, uint32_t* auto_lanes);
+
 /* 1 if racc_hip_options::kernel_variant = n selects a kernel of this build (0 = the default always does; the earlier
  * generations and ablations exist only in a `make EXPERIMENTAL=1` build), else 0.  Needs no GPU. */
 int racc_hip_variant_available(uint32_t kernel_variant);

@@ -108,7 +108,7 @@ struct Lane {
     uint32_t ringHead = 0, ringCount = 0;
     // host-buffer path, sliced: the kernels of consecutive slices go to the lane and its two helpers in turn, so that one
     // slice's drain runs beside the next slice's bulk (each with half a grid), created on first use
-    Lane* helper[2] = {nullptr, nullptr};
+    Lane* helper[3] = {nullptr, nullptr, nullptr};      // (the third only when the runtime has >= 8 hardware queues)
     uint32_t forceWavesPerSimd = 0;      // != 0: grid size of this (helper-rotated) launch
 };
 constexpr uint32_t kTimeRing = 256;
@@ -124,6 +124,9 @@ struct racc_hip_ctx {
     uint32_t* devTrips = nullptr;        // the device alias of the same word
     std::atomic<uint32_t> seenTrips{0};
     std::atomic<uint32_t> nextLane{0};   // RACC_HIP_LANE_AUTO: round robin
+    uint32_t autoLanes = 3;              // ... over this many lanes
+    uint32_t overlapWaves = 2;           // waves per SIMD of a launch that finds another lane's launch running
+    int hwQueues = 4;                    // GPU_MAX_HW_QUEUES as this process's HIP runtime was started with
     uint32_t maxIters = 1u << 24;        // RACC_MAX_ITERS overrides (tests)
 };
 
@@ -403,7 +406,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     const uint32_t ldsBytes = uint32_t(v.cacheNodes) * 64u + uint32_t(v.ldsLevels) * uint32_t(v.block) * 4u + (v.ldsLevels > 32 ? 272u : 0u) +
                               uint32_t(v.stagePerWave) * uint32_t(v.block / 64);
     // Persistent grid: as many waves as the LDS allows (5 per SIMD with the default kernel) when the GPU is otherwise idle.
-    // When another lane's launch is still running — a caller issuing batch after batch — a launch takes 2 per SIMD:
+    // When another lane's launch is still running — a caller issuing batch after batch — a launch takes 2 per SIMD (1 with six lanes in rotation):
     // two or three launches are then co-resident, each one's drain (its last, longest rays: ~0.13 ms during which most of
     // its waves have nothing left) runs beside the others' bulk instead of leaving the machine empty.  Measured on 1M-ray
     // diffuse batches (tools/gpu_overlap.py): 0.378 ms per batch one at a time; back to back over 3 lanes 0.294 with full
@@ -415,7 +418,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
         //  3.42 Grays/s end to end with full grids, 3.08 with halved ones)
         for (uint32_t i = 0; i < ctx->opts.lanes && count <= (2u << 20); ++i) {
             const Lane& other = ctx->lanes[i];
-            if (&other != &lane && other.everLaunched.load(std::memory_order_relaxed) && hipEventQuery(other.done) == hipErrorNotReady) { wavesPerSimd = 2u; break; }
+            if (&other != &lane && other.everLaunched.load(std::memory_order_relaxed) && hipEventQuery(other.done) == hipErrorNotReady) { wavesPerSimd = ctx->overlapWaves; break; }
         }
         (void)hipGetLastError();      // hipErrorNotReady is not an error
     }
@@ -580,6 +583,13 @@ const char* racc_hip_version(void) { return "racc-hip 0.2 (gfx950, experimental 
 const char* racc_hip_version(void) { return "racc-hip 0.2 (gfx950)"; }
 #endif
 
+int racc_hip_lane_count(const racc_hip_ctx* ctx, uint32_t* lanes, uint32_t* auto_lanes) {
+    if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
+    if (lanes) *lanes = ctx->opts.lanes;
+    if (auto_lanes) *auto_lanes = ctx->autoLanes;
+    return RACC_HIP_OK;
+}
+
 int racc_hip_variant_available(uint32_t kernel_variant) {
     if (kernel_variant == 0u) return 1;
     return kernel_variant <= uint32_t(kNumVariants) && kVariants[kernel_variant - 1].kernel != nullptr ? 1 : 0;
@@ -622,8 +632,24 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
         delete ctx;
         return fail(RACC_HIP_ERR_INVALID, "kernel_variant is not in this build (experimental kernels: make EXPERIMENTAL=1)");
     }
-    if (!ctx->opts.lanes) ctx->opts.lanes = 4;                       // RayAccelerator.cpp:436
-    if (ctx->opts.lanes > RACC_HIP_MAX_LANES) ctx->opts.lanes = RACC_HIP_MAX_LANES;
+    // How many launches to keep in flight.  HIP streams share hardware queues (GPU_MAX_HW_QUEUES, 4 unless the environment says
+    // otherwise), and kernels of two streams on one hardware queue do not overlap.  Measured on 1M-ray diffuse batches back to
+    // back (tools/gpu_overlap.py), ms per batch: 4 queues: 3 lanes x 2 waves per SIMD 0.260, 4 x 2 0.322, 6 x 1 0.349;
+    // 8 queues: 3 x 2 0.260, 4 x 2 0.253, 6 x 1 0.245-0.251, 7 x 1 0.247, 8 x 1 0.32; 16 queues: 6 x 1 0.248, 8 x 1 0.254.
+    // So: six thin launches when the runtime was given >= 8 hardware queues, three otherwise.
+    {
+        const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+        const int hwQueues = q ? std::atoi(q) : 4;
+        ctx->hwQueues = hwQueues;
+        const bool defaultLanes = ctx->opts.lanes == 0;
+        ctx->autoLanes = hwQueues >= 8 ? 6u : 3u;
+        if (const char* r = std::getenv("RACC_AUTO_LANES")) if (std::atoi(r) > 0) ctx->autoLanes = uint32_t(std::atoi(r));
+        if (defaultLanes && ctx->autoLanes > 4u) ctx->opts.lanes = ctx->autoLanes;
+        if (!ctx->opts.lanes) ctx->opts.lanes = 4;                       // RayAccelerator.cpp:436
+        if (ctx->opts.lanes > RACC_HIP_MAX_LANES) ctx->opts.lanes = RACC_HIP_MAX_LANES;
+        if (ctx->autoLanes > ctx->opts.lanes) ctx->autoLanes = ctx->opts.lanes;
+        ctx->overlapWaves = ctx->autoLanes >= 5u ? 1u : 2u;
+    }
     if (ctx->opts.waves_per_simd > 8) ctx->opts.waves_per_simd = 8;
     if (ctx->opts.refill_min > 64) ctx->opts.refill_min = 64;
     if (ctx->opts.leaf_min > 64) ctx->opts.leaf_min = 64;
@@ -873,16 +899,26 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
         HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
         return checkWatchdog(ctx);
     }
-    if (!l.copyIn) HIP_TRY(hipStreamCreateWithFlags(&l.copyIn, hipStreamNonBlocking), "hipStreamCreate");
-    if (!l.copyOut) HIP_TRY(hipStreamCreateWithFlags(&l.copyOut, hipStreamNonBlocking), "hipStreamCreate");
-    for (Lane*& h : l.helper)
-        if (!h) {
+    // The five streams of the pipeline — three for the slices' kernels, copy-in, copy-out — should sit on five hardware
+    // queues.  HIP hands queues out in creation order: with >= 8 of them the kernels go to three helper lanes created here in
+    // a row with the copy streams (the lane's own stream, created with the context, may share a queue with any of them: with
+    // six lanes and 8 queues it did, 0.87 instead of 1.03 Grays/s); with the default 4 the lane's own stream and two helpers.
+    const uint32_t nHelpers = ctx->hwQueues >= 8 ? 3u : 2u;
+    if (nHelpers == 2u) {      // 4 queues: copy streams first (measured: the other order costs 5 %)
+        if (!l.copyIn) HIP_TRY(hipStreamCreateWithFlags(&l.copyIn, hipStreamNonBlocking), "hipStreamCreate");
+        if (!l.copyOut) HIP_TRY(hipStreamCreateWithFlags(&l.copyOut, hipStreamNonBlocking), "hipStreamCreate");
+    }
+    for (uint32_t i = 0; i < nHelpers; ++i)
+        if (!l.helper[i]) {
+            Lane*& h = l.helper[i];
             h = new (std::nothrow) Lane();
             if (!h) return fail(RACC_HIP_ERR_NOMEM, "out of host memory");
             const hipError_t e = initLane(*h, false);
             if (e != hipSuccess) return fail(RACC_HIP_ERR_DEVICE, "helper lane setup", e);
         }
-    Lane* const run[3] = {&l, l.helper[0], l.helper[1]};
+    Lane* const run[3] = {nHelpers == 3u ? l.helper[2] : &l, l.helper[0], l.helper[1]};
+    if (!l.copyIn) HIP_TRY(hipStreamCreateWithFlags(&l.copyIn, hipStreamNonBlocking), "hipStreamCreate");
+    if (!l.copyOut) HIP_TRY(hipStreamCreateWithFlags(&l.copyOut, hipStreamNonBlocking), "hipStreamCreate");
     // Cut into slices so that the PCIe copy of slice k+1 (in) and of slice k-1 (out) run beside the kernel of slice k (PCIe is
     // full duplex; a 1M-ray batch is 32 MiB in, 16 MiB out), the kernels on the lane and its two helpers in turn so that one
     // slice's drain runs beside the next one's bulk.  Measured on page-locked arrays: 1.04 Grays/s at 1M rays, 1.37 at 4M
@@ -918,7 +954,7 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
         HIP_TRY(copyRange(1, g0, g1, l.copyOut), "D2H results");
         r.forceWavesPerSimd = 0u;
     }
-    for (Lane* h : l.helper) HIP_TRY(hipStreamSynchronize(h->stream), "hipStreamSynchronize");
+    for (Lane* h : l.helper) if (h) HIP_TRY(hipStreamSynchronize(h->stream), "hipStreamSynchronize");
     HIP_TRY(hipStreamSynchronize(l.copyOut), "hipStreamSynchronize");
     HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
     return checkWatchdog(ctx);
@@ -927,11 +963,8 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
 int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
                               const void* d_rays, void* d_results, uint32_t count, uint32_t lane, void* stream) {
     if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
-    // round robin over (up to) three lanes: consecutive launches overlap; a fourth in flight measured slower (3.35 vs 3.84 Grays/s)
-    if (lane == RACC_HIP_LANE_AUTO) {
-        static const uint32_t rot = getenv("RACC_AUTO_LANES") ? uint32_t(atoi(getenv("RACC_AUTO_LANES"))) : 3u;
-        lane = ctx->nextLane.fetch_add(1u) % (ctx->opts.lanes < rot ? ctx->opts.lanes : rot);
-    }
+    // round robin over the lanes in rotation (racc_hip_create): consecutive launches overlap
+    if (lane == RACC_HIP_LANE_AUTO) lane = ctx->nextLane.fetch_add(1u) % ctx->autoLanes;
     if (int rc = checkLane(ctx, lane)) return rc;
     if (!scene) return fail(RACC_HIP_ERR_INVALID, "scene is NULL");
     if (!count) return RACC_HIP_OK;

@@ -62,6 +62,7 @@ ABI = {
     "racc_hip_last_error": (C.c_char_p, []),
     "racc_hip_version": (C.c_char_p, []),
     "racc_hip_variant_available": (_i, [_u32]),
+    "racc_hip_lane_count": (_i, [_vp, _P(_u32), _P(_u32)]),
     "racc_hip_device_count": (_i, [_P(_i)]),
     "racc_hip_create": (_i, [_i, _P(Options), _P(_vp)]),
     "racc_hip_destroy": (_i, [_vp]),
@@ -275,10 +276,12 @@ class Context:
         o.drain_prefetch = drain_prefetch
         o.leaf_step = leaf_step
         o.wide_below = wide_below
-        self.lanes = lanes or 4
         h = C.c_void_p()
         _check(lib.racc_hip_create(device, C.byref(o), C.byref(h)))
         self._h = h
+        n, rot = C.c_uint32(), C.c_uint32()
+        _check(lib.racc_hip_lane_count(h, C.byref(n), C.byref(rot)))
+        self.lanes, self.auto_lanes = int(n.value), int(rot.value)      # lanes the context has / lanes LANE_AUTO rotates over
         self.device = device
 
     def destroy(self):

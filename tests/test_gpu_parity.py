@@ -405,6 +405,41 @@ def test_lane_auto_rotation(gpu_ctx, small):
         d_r.free(); d_o.free()
 
 
+def test_six_lanes_in_rotation_with_eight_hardware_queues():
+    """GPU_MAX_HW_QUEUES >= 8 (read by the HIP runtime when it starts, so: a fresh process): the engine defaults to six lanes,
+    RACC_HIP_LANE_AUTO rotates over all of them with thin grids; twelve batches issued back to back, every one bit-exact."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np
+        import rayaccel_amd as ra
+        from rayaccel_amd import synth
+        from oracle import oracle as orc
+        sc = synth.battlefield_synth(grid=40, boxes=32, quads=100)
+        host = ra.HostScene(sc["vertices"], sc["indices"])
+        prim, _ = synth.primary_rays(sc["camera"], 256, 256)
+        ref = orc.traverse(host.blobs(), prim, env=sc["env"])
+        with ra.Context(device=0) as ctx:
+            assert (ctx.lanes, ctx.auto_lanes) == (6, 6), (ctx.lanes, ctx.auto_lanes)
+            scene = ctx.upload_scene(host.nodes, host.pairs, host.remap); env = ctx.create_environment(sc["env"])
+            d_r = ctx.alloc(prim.nbytes); d_r.upload(prim)
+            outs = [ctx.alloc(len(prim) * 16) for _ in range(12)]
+            for o in outs:
+                ctx.intersect_device(scene, env, d_r.ptr, o.ptr, len(prim), lane=ra.LANE_AUTO)
+            ctx.wait(ra.LANE_AUTO)
+            assert ctx.launch_info(5)["waves_per_simd"] == 1
+            for o in outs:
+                got = o.download(orc.RESULT_DTYPE, len(prim))
+                assert np.array_equal(got["triangle"], ref["triangle"]) and np.array_equal(got["t"][ref["triangle"] != 0xFFFFFFFF].view(np.uint32), ref["t"][ref["triangle"] != 0xFFFFFFFF].view(np.uint32))
+        with ra.Context(device=0, lanes=2) as ctx:
+            assert (ctx.lanes, ctx.auto_lanes) == (2, 2)
+        print("ok")
+    """)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env.pop("RACC_AUTO_LANES", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_one_lane_from_two_caller_streams(gpu_ctx, small):
     """A lane owns one ray cursor: two launches on the SAME lane from two different caller streams used to race on it
     (ADVICE r1).  The engine now makes the second wait for the first on the device; both must be exact, many times over."""
