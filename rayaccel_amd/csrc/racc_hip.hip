@@ -453,13 +453,13 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.chunk = optOr(ctx->opts.chunk, 64u * uint32_t(v.slots));
     if (a.chunk > 65536u) a.chunk = 65536u;      // grid waves x chunk (the statically assigned first chunks) must stay far below 2^32
     a.refillMin = optOr(ctx->opts.refill_min, 20u);      // tools/gpu_policy_sweep.py: 12-20 idle lanes beat 32 by 2 % (4M-ray launch) to 3 % (1M-ray launches back to back); 44: -15 %
-    a.leafMin = optOr(ctx->opts.leaf_min, 12u);
+    a.leafMin = optOr(ctx->opts.leaf_min, v.wide ? 6u : 12u);      // (the wide kernels' optimum, tools/gpu_policy_sweep.py: 4M 1.115 vs 1.15 ms, back to back 0.265 vs 0.278)
     a.maxIters = ctx->maxIters;
     a.trips = ctx->devTrips;
     a.tailActive = ctx->opts.tail_active ? (ctx->opts.tail_active > 64u ? 0u : ctx->opts.tail_active) : 32u;   // >64 disables
     a.regroup = optOr(ctx->opts.regroup_period, 8u);
     a.thinReps = optOr(ctx->opts.thin_reps, 8u);
-    a.innerReps = optOr(ctx->opts.inner_reps, 3u);
+    a.innerReps = optOr(ctx->opts.inner_reps, v.wide ? 2u : 3u);
     a.coopNum = ctx->opts.coop_same_pct ? (ctx->opts.coop_same_pct > 100u ? 0u : ctx->opts.coop_same_pct) : 20u;   // > 100 disables the cooperative fetch
     a.coopDen = 100u;
     a.leafInCpp = ctx->opts.leaf_step == 2u ? 1u : 0u;
