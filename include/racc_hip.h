@@ -71,6 +71,12 @@ typedef struct racc_hip_options {
                                   context's kernel: a launch of <= ~200k rays is all dependent chain, and the wide tree halves
                                   it (27k-ray launch, the reference's stream size: 0.10 instead of 0.12 ms).  Results: see
                                   kernel_variant 45.  0 => never (default) */
+    uint32_t chain_launches;   /* 0/1 => device-resident batches issued on the engine's own streams (racc_hip_intersect_device with
+                                  stream = NULL) are chained: waves that run out of rays in one batch go on with the next one
+                                  issued, so a sequence of batches runs like one long launch (no drain between them).  Contract:
+                                  a batch's ray and result arrays must stay untouched from the call until racc_hip_wait /
+                                  racc_hip_synchronize has returned.  2 => off: every launch stands alone, the lanes' launches
+                                  merely overlap (and an array may be reused as soon as its own lane's launch is waited for) */
 } racc_hip_options;
 
 typedef struct racc_hip_scene_info {

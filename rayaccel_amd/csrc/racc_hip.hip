@@ -69,6 +69,16 @@ __global__ void __launch_bounds__(256) envShadeKernel(float4* results, uint32_t 
     }
 }
 
+// Chained launches: writes launch `idx`'s descriptor into the ring (device memory: a drained wave reads it at L2 speed; host-mapped
+// memory cost every such wave six PCIe round trips) and links it behind its predecessor.  One thread, on the context's control stream.
+__global__ void chainPublishKernel(ChainDesc* ring, uint32_t idx, const float4* rays, float4* results, uint32_t* cursor, uint32_t count,
+                                   uint32_t dynBase, int pred) {
+    ChainDesc& d = ring[idx];
+    d.rays = rays; d.results = results; d.cursor = cursor; d.count = count; d.dynBase = dynBase;
+    __hip_atomic_store(&d.next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pred >= 0) __hip_atomic_store(&ring[pred].next, idx + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 thread_local char g_msg[512];
 
 int fail(int code, const char* what, hipError_t e = hipSuccess) {
@@ -127,6 +137,17 @@ struct racc_hip_ctx {
     uint32_t autoLanes = 3;              // ... over this many lanes
     uint32_t overlapWaves = 2;           // waves per SIMD of a launch that finds another lane's launch running
     int hwQueues = 4;                    // GPU_MAX_HW_QUEUES as this process's HIP runtime was started with
+    // chained launches (launchTraverse): a ring of descriptors in host-mapped memory, one fresh cursor word per launch
+    static constexpr uint32_t kChainRing = 256;
+    ChainDesc* chainDev = nullptr;       // the ring of descriptors (device memory, written by chainPublishKernel)
+    hipStream_t chainStream = nullptr;   // control stream of the publish kernels
+    uint32_t* chainCursors = nullptr;    // device: kChainRing x 16 words (cursor at word 0), all zero between ring laps
+    hipEvent_t chainDone[kChainRing] = {};   // recorded right after each chained kernel
+    bool chainUsed[kChainRing] = {};
+    uint32_t chainHead = 0;              // launches so far
+    std::mutex chainMutex;
+    struct { const racc_hip_scene* scene = nullptr; const racc_hip_env* env = nullptr; const void* kernel = nullptr; uint32_t idx = 0; bool valid = false; } chainLast;
+    bool chainEnabled = true;            // RACC_CHAIN=0 switches it off
     uint32_t maxIters = 1u << 24;        // RACC_MAX_ITERS overrides (tests)
 };
 
@@ -319,6 +340,7 @@ struct Variant {
     int reserved = 0;          // LDS levels the kernel keeps for itself (V5: the sentinel; V6: sentinel + trash level)
     int stagePerWave = 0;      // bytes of LDS-DMA stage per wave (V6 COOP)
     bool wide = false;         // traverses the 4-wide device format (V9)
+    bool chains = false;       // its waves can move on to the next launch of a chain (V8)
     int stackLevels() const { return (ldsLevels > 32 ? ldsLevels - (kRecFields + 1) : ldsLevels / slots) - reserved; }   // V3 rows fold the record words into ldsLevels
 };
 // kernel_variant n selects kVariants[n-1]; 0 selects the default (V8).  LDS per workgroup = cacheNodes*64 + ldsLevels*block*4
@@ -370,10 +392,10 @@ const Variant kVariants[] = {
     {256, 10, 0, RACC_X(traverseKernelV7<256, 9, false>), false, true, 1, 2, 4 * 1040},           // 38: V7: V6 as refill-loop around work-loop (no per-iteration register copies), thin waves fetch per lane
     {256, 10, 0, RACC_X(traverseKernelV7<256, 9, true>), false, true, 1, 2, 4 * 1040},            // 39: variant 38 + statistics (debug)
     {256, 14, 0, RACC_X(traverseKernelV7<256, 13, false>), false, true, 1, 2, 4 * 1040},          // 40: V7, 12-entry LDS stack (5 workgroups per CU)
-    {256, 10, 0, traverseKernelV8<256, 9, false>, false, true, 1, 2, 4 * 1040},           // 41: V8 with an 8-entry LDS stack (exercises the DEEP door and the spill: 2.6 % of the bench rays)
-    {256, 14, 0, traverseKernelV8<256, 13, true>, false, true, 1, 2, 4 * 1040},           // 42: variant 43 + statistics (debug; only the C++ parts count: refills, rays loaded, waves)
-    {256, 14, 0, traverseKernelV8<256, 13, false>, false, true, 1, 2, 4 * 1040},          // 43: V8, 12-entry LDS stack: the default
-    {256, 14, 0, traverseKernelV8<256, 13, false, false>, false, false, 1, 2, 4 * 1040},  // 44: variant 43 with the probe-image lookup in its own epilogue (no envShadeKernel launch)
+    {256, 10, 0, traverseKernelV8<256, 9, false>, false, true, 1, 2, 4 * 1040, false, true},           // 41: V8 with an 8-entry LDS stack (exercises the DEEP door and the spill: 2.6 % of the bench rays)
+    {256, 14, 0, traverseKernelV8<256, 13, true>, false, true, 1, 2, 4 * 1040, false, true},           // 42: variant 43 + statistics (debug; only the C++ parts count: refills, rays loaded, waves)
+    {256, 14, 0, traverseKernelV8<256, 13, false>, false, true, 1, 2, 4 * 1040, false, true},          // 43: V8, 12-entry LDS stack: the default
+    {256, 14, 0, traverseKernelV8<256, 13, false, false>, false, false, 1, 2, 4 * 1040, false, true},  // 44: variant 43 with the probe-image lookup in its own epilogue (no envShadeKernel launch)
     {256, 19, 0, traverseKernelV9<256, 19, false, true>, false, true, 1, 1, 8 * 1040, true},    // 45: V9 (4-wide nodes, hot loop in assembly), 18-entry LDS stack: 3 workgroups per CU
     {256, 7, 0, traverseKernelV9<256, 7, false, false>, false, true, 1, 1, 8 * 1040, true},     // 46: V9 in plain C++, 6-entry LDS stack + spill: 4 workgroups per CU (exercises the spill)
     {256, 19, 0, traverseKernelV9<256, 19, true, false>, false, true, 1, 1, 8 * 1040, true},    // 47: V9 in plain C++ + statistics (debug)
@@ -396,8 +418,10 @@ const Variant& pickVariant(const racc_hip_ctx* ctx, uint32_t treeHeight) {
     return kVariants[kDefaultVariant - 1];
 }
 
+// mayChain: the batch is resident and final NOW (a device-resident batch issued on one of the engine's own streams), so waves of
+// the launch issued before it may start on it before its own kernel does (DESIGN.md §3 "Chained launches").
 int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc_hip_scene* scene, const racc_hip_env* env,
-                   const void* dRays, void* dResults, uint32_t count) {
+                   const void* dRays, void* dResults, uint32_t count, bool mayChain = false) {
     if (!count) return RACC_HIP_OK;
     const Variant* vp = &pickVariant(ctx, scene->info.inner_height);
     if (count < ctx->opts.wide_below && !vp->wide) vp = &kVariants[kWideVariant - 1];      // small launch: the shorter dependent chain wins
@@ -411,6 +435,29 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     // its waves have nothing left) runs beside the others' bulk instead of leaving the machine empty.  Measured on 1M-ray
     // diffuse batches (tools/gpu_overlap.py): 0.378 ms per batch one at a time; back to back over 3 lanes 0.294 with full
     // grids, 0.271 with 3 waves per SIMD each, 0.266 with 2 (0.33 / 0.28 with four / five lanes in rotation: three it is).
+    // ---- chained launches: is the launch issued just before this one (any lane) still running on the same scene?
+    const bool chain = mayChain && v.chains && ctx->chainEnabled && ctx->chainDev != nullptr && count < 0x80000000u;      // (bit 31 of a ray index tags the batch)
+    std::unique_lock<std::mutex> chainGuard(ctx->chainMutex, std::defer_lock);
+    uint32_t chainIdx = 0;
+    int chainPred = -1;
+    if (chain) {
+        chainGuard.lock();
+        chainIdx = ctx->chainHead % racc_hip_ctx::kChainRing;
+        if (chainIdx == 0 && ctx->chainHead != 0) {      // a lap of the ring: every cursor word must be zero again before it is handed out
+            for (uint32_t i = 0; i < racc_hip_ctx::kChainRing; ++i)
+                if (ctx->chainUsed[i]) { HIP_TRY(hipEventSynchronize(ctx->chainDone[i]), "hipEventSynchronize(chain)"); ctx->chainUsed[i] = false; }
+            HIP_TRY(hipStreamSynchronize(ctx->chainStream), "hipStreamSynchronize(chain)");
+            HIP_TRY(hipMemset(ctx->chainCursors, 0, size_t(racc_hip_ctx::kChainRing) * 64), "hipMemset(chain cursors)");
+            // ... and no descriptor may keep a link of the lap before: a kernel can look at its own descriptor before the publish
+            // kernel of its launch has run, and must then find "no next", not last lap's successor
+            HIP_TRY(hipMemset(ctx->chainDev, 0, sizeof(ChainDesc) * racc_hip_ctx::kChainRing), "hipMemset(chain ring)");
+            ctx->chainLast.valid = false;
+        }
+        if (ctx->chainLast.valid && ctx->chainLast.scene == scene && ctx->chainLast.env == env && ctx->chainLast.kernel == reinterpret_cast<const void*>(v.kernel) &&
+            hipEventQuery(ctx->chainDone[ctx->chainLast.idx]) == hipErrorNotReady)
+            chainPred = int(ctx->chainLast.idx);
+        (void)hipGetLastError();      // hipErrorNotReady is not an error
+    }
     uint32_t wavesPerSimd = ctx->opts.waves_per_simd ? ctx->opts.waves_per_simd : lane.forceWavesPerSimd;
     if (!wavesPerSimd) {
         wavesPerSimd = 6u;
@@ -448,6 +495,12 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.env = env ? env->pixels : nullptr;
     a.envW = env ? env->width : 0; a.envH = env ? env->height : 0;
     a.cursor = lane.cursor;
+    a.chain = nullptr; a.chainRing = nullptr; a.rearm = 1u;
+    if (chain) {
+        a.cursor = ctx->chainCursors + size_t(chainIdx) * 16;
+        a.rearm = 0u;
+        a.chain = ctx->chainDev + chainIdx; a.chainRing = ctx->chainDev;
+    }
     a.spill = lane.spill;
     a.spillStride = gridThreads;
     a.chunk = optOr(ctx->opts.chunk, 64u * uint32_t(v.slots));
@@ -477,6 +530,19 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
         HIP_TRY(hipEventRecord(lane.ring[2 * lane.ringHead + 1], stream), "hipEventRecord");
         lane.ringHead = (lane.ringHead + 1u) % kTimeRing;
         if (lane.ringCount < kTimeRing) ++lane.ringCount;
+    }
+    if (chain) {
+        // the descriptor, and the link behind the predecessor: from here on the waves of every earlier launch of the chain may take
+        // this batch's rays, so whatever follows on this stream (the miss shading, the lane's `done`) must see those kernels ended
+        hipLaunchKernelGGL(chainPublishKernel, dim3(1), dim3(1), 0, ctx->chainStream, ctx->chainDev, chainIdx, a.rays, a.results, a.cursor, count,
+                           blocks * uint32_t(v.block / 64) * a.chunk, chainPred);
+        HIP_TRY(hipGetLastError(), "launch chainPublishKernel");
+        if (chainPred >= 0) HIP_TRY(hipStreamWaitEvent(stream, ctx->chainDone[chainPred], 0), "hipStreamWaitEvent(chain)");
+        HIP_TRY(hipEventRecord(ctx->chainDone[chainIdx], stream), "hipEventRecord(chain)");      // = this kernel and every one before it in the chain has ended
+        ctx->chainUsed[chainIdx] = true;
+        ctx->chainLast.scene = scene; ctx->chainLast.env = env; ctx->chainLast.kernel = reinterpret_cast<const void*>(v.kernel);
+        ctx->chainLast.idx = chainIdx; ctx->chainLast.valid = true;
+        ++ctx->chainHead;
     }
     lane.pendingEnv = v.deferEnv && env != nullptr;
     lane.info.grid_blocks = blocks;
@@ -642,7 +708,11 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
         const int hwQueues = q ? std::atoi(q) : 4;
         ctx->hwQueues = hwQueues;
         const bool defaultLanes = ctx->opts.lanes == 0;
-        ctx->autoLanes = hwQueues >= 8 ? 6u : 3u;
+        ctx->chainEnabled = ctx->opts.chain_launches != 2u;
+        if (const char* c = std::getenv("RACC_CHAIN")) ctx->chainEnabled = std::atoi(c) != 0;
+        // chained launches (launchTraverse) need no thin grids: three lanes are enough to keep successors queued (measured, 1M-ray
+        // batches: 20 in a row 0.285 ms each with 3 lanes, 0.292 with 2, 0.32 with 4, 0.42 with 6; 200 in a row 0.242 / 0.245 / - / 0.273)
+        ctx->autoLanes = ctx->chainEnabled ? 3u : (hwQueues >= 8 ? 6u : 3u);
         if (const char* r = std::getenv("RACC_AUTO_LANES")) if (std::atoi(r) > 0) ctx->autoLanes = uint32_t(std::atoi(r));
         if (defaultLanes && ctx->autoLanes > 4u) ctx->opts.lanes = ctx->autoLanes;
         if (!ctx->opts.lanes) ctx->opts.lanes = 4;                       // RayAccelerator.cpp:436
@@ -663,6 +733,21 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
         if (e1 != hipSuccess) { racc_hip_destroy(ctx); return fail(RACC_HIP_ERR_DEVICE, "watchdog word", e1); }
         if (const char* m = std::getenv("RACC_MAX_ITERS")) { const long long v = std::atoll(m); if (v > 0 && v < (1ll << 31)) ctx->maxIters = uint32_t(v); }
     }
+    {
+        ctx->chainEnabled = ctx->opts.chain_launches != 2u;
+        if (const char* c = std::getenv("RACC_CHAIN")) ctx->chainEnabled = std::atoi(c) != 0;
+        hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&ctx->chainDev), sizeof(ChainDesc) * racc_hip_ctx::kChainRing);
+        if (e1 == hipSuccess) e1 = hipMemset(ctx->chainDev, 0, sizeof(ChainDesc) * racc_hip_ctx::kChainRing);
+        if (e1 == hipSuccess) {      // highest priority: a publish kernel must not wait behind the persistent waves it is meant to feed
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            e1 = hipStreamCreateWithPriority(&ctx->chainStream, hipStreamNonBlocking, hi);
+        }
+        if (e1 == hipSuccess) e1 = hipMalloc(reinterpret_cast<void**>(&ctx->chainCursors), size_t(racc_hip_ctx::kChainRing) * 64);
+        if (e1 == hipSuccess) e1 = hipMemset(ctx->chainCursors, 0, size_t(racc_hip_ctx::kChainRing) * 64);
+        for (uint32_t i = 0; i < racc_hip_ctx::kChainRing && e1 == hipSuccess; ++i) e1 = hipEventCreateWithFlags(&ctx->chainDone[i], hipEventDisableTiming);
+        if (e1 != hipSuccess) { racc_hip_destroy(ctx); return fail(RACC_HIP_ERR_DEVICE, "chain ring", e1); }
+    }
     *out = ctx;
     return RACC_HIP_OK;
 }
@@ -672,6 +757,10 @@ int racc_hip_destroy(racc_hip_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();              // launches given a caller's own stream (racc_hip_intersect_device) included
     if (ctx->hostTrips) hipHostFree(ctx->hostTrips);
+    if (ctx->chainDev) hipFree(ctx->chainDev);
+    if (ctx->chainStream) hipStreamDestroy(ctx->chainStream);
+    if (ctx->chainCursors) hipFree(ctx->chainCursors);
+    for (hipEvent_t ev : ctx->chainDone) if (ev) hipEventDestroy(ev);
     for (Lane& l : ctx->lanes) freeLane(l);
     delete ctx;
     return RACC_HIP_OK;
@@ -730,6 +819,7 @@ int racc_hip_scene_upload(racc_hip_ctx* ctx, const void* nodes64, uint32_t node_
 
 int racc_hip_scene_free(racc_hip_ctx* ctx, racc_hip_scene* s) {
     if (!s) return RACC_HIP_OK;
+    if (ctx) { std::lock_guard<std::mutex> g(ctx->chainMutex); if (ctx->chainLast.scene == s) ctx->chainLast.valid = false; }
     if (ctx) hipSetDevice(ctx->device);
     if (s->nodes) hipFree(s->nodes);
     if (s->nodesWide) hipFree(s->nodesWide);
@@ -764,6 +854,7 @@ int racc_hip_env_upload(racc_hip_ctx* ctx, const float* rgba, uint32_t width, ui
 
 int racc_hip_env_free(racc_hip_ctx* ctx, racc_hip_env* env) {
     if (!env) return RACC_HIP_OK;
+    if (ctx) { std::lock_guard<std::mutex> g(ctx->chainMutex); if (ctx->chainLast.env == env) ctx->chainLast.valid = false; }
     if (ctx) hipSetDevice(ctx->device);
     if (env->pixels) hipFree(env->pixels);
     delete env;
@@ -973,7 +1064,7 @@ int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, co
     Lane& l = ctx->lanes[lane];
     std::lock_guard<std::mutex> guard(l.mutex);
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : l.stream;
-    if (int rc = launchTraverse(ctx, l, st, scene, env, d_rays, d_results, count)) return rc;
+    if (int rc = launchTraverse(ctx, l, st, scene, env, d_rays, d_results, count, /*mayChain=*/stream == nullptr)) return rc;
     return launchEnvShade(ctx, l, st, env, d_results, count);
 }
 

@@ -406,8 +406,9 @@ def test_lane_auto_rotation(gpu_ctx, small):
 
 
 def test_six_lanes_in_rotation_with_eight_hardware_queues():
-    """GPU_MAX_HW_QUEUES >= 8 (read by the HIP runtime when it starts, so: a fresh process): the engine defaults to six lanes,
-    RACC_HIP_LANE_AUTO rotates over all of them with thin grids; twelve batches issued back to back, every one bit-exact."""
+    """GPU_MAX_HW_QUEUES >= 8 (read by the HIP runtime when it starts, so: a fresh process) and launches not chained: the engine
+    defaults to six lanes, RACC_HIP_LANE_AUTO rotates over all of them with thin grids; twelve batches issued back to back, every
+    one bit-exact.  (Chained launches, the default, keep three lanes whatever the queue count.)"""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
         import numpy as np
@@ -419,6 +420,8 @@ def test_six_lanes_in_rotation_with_eight_hardware_queues():
         prim, _ = synth.primary_rays(sc["camera"], 256, 256)
         ref = orc.traverse(host.blobs(), prim, env=sc["env"])
         with ra.Context(device=0) as ctx:
+            assert ctx.auto_lanes == 3, (ctx.lanes, ctx.auto_lanes)
+        with ra.Context(device=0, chain_launches=2) as ctx:
             assert (ctx.lanes, ctx.auto_lanes) == (6, 6), (ctx.lanes, ctx.auto_lanes)
             scene = ctx.upload_scene(host.nodes, host.pairs, host.remap); env = ctx.create_environment(sc["env"])
             d_r = ctx.alloc(prim.nbytes); d_r.upload(prim)
@@ -430,7 +433,7 @@ def test_six_lanes_in_rotation_with_eight_hardware_queues():
             for o in outs:
                 got = o.download(orc.RESULT_DTYPE, len(prim))
                 assert np.array_equal(got["triangle"], ref["triangle"]) and np.array_equal(got["t"][ref["triangle"] != 0xFFFFFFFF].view(np.uint32), ref["t"][ref["triangle"] != 0xFFFFFFFF].view(np.uint32))
-        with ra.Context(device=0, lanes=2) as ctx:
+        with ra.Context(device=0, lanes=2, chain_launches=2) as ctx:
             assert (ctx.lanes, ctx.auto_lanes) == (2, 2)
         print("ok")
     """)
@@ -438,6 +441,66 @@ def test_six_lanes_in_rotation_with_eight_hardware_queues():
     env.pop("RACC_AUTO_LANES", None)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_chained_launches(small_scene, small_host, small):
+    """Chained launches (the default for device-resident batches on the engine's streams): waves that run out of rays in one batch
+    go on with the next one issued.  Sequences of batches of very different sizes, with invalid rays, on two scenes alternately
+    (a different scene breaks the chain), more launches than the descriptor ring holds (it laps), waits in between — every batch
+    bit-exact, and identical to the same sequence with chaining off."""
+    batches = _batches(small)
+    rng = np.random.default_rng(5)
+    pool = np.concatenate([batches["primary"], batches["diffuse"], batches["random"]])
+    pool = pool[rng.permutation(len(pool))]
+    pool["dir"][::997] = np.nan                       # invalid rays: misses with rgb = 0
+    ref = orc.traverse(small["blobs"], pool, env=small_scene["env"])
+    other = synth.battlefield_synth(grid=24, boxes=8, quads=30)
+    other_host = ra.HostScene(other["vertices"], other["indices"])
+    ref_other = orc.traverse(other_host.blobs(), pool[:5000], env=small_scene["env"])
+    for chain in (0, 2):
+        with ra.Context(device=0, chain_launches=chain) as ctx:
+            scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
+            scene2 = ctx.upload_scene(other_host.nodes, other_host.pairs, other_host.remap)
+            env = ctx.create_environment(small_scene["env"])
+            d_pool = ctx.alloc(pool.nbytes); d_pool.upload(pool)
+            issued = []
+            for k in range(300):
+                n = int(rng.choice([1, 63, 64, 65, 1000, 4097, 20000, int(rng.integers(1, len(pool)))]))
+                off = int(rng.integers(0, len(pool) - n + 1))
+                d_o = ctx.alloc(n * 16)
+                if k % 37 == 36:            # another scene in between: no chain across it
+                    m = min(n, 5000)
+                    ctx.intersect_device(scene2, env, d_pool.ptr, d_o.ptr, m, lane=ra.LANE_AUTO)
+                    issued.append((d_o, 0, m, ref_other))
+                else:
+                    ctx.intersect_device(scene, env, d_pool.ptr + off * 32, d_o.ptr, n, lane=ra.LANE_AUTO)
+                    issued.append((d_o, off, n, ref))
+                if k % 53 == 52:
+                    ctx.wait(ra.LANE_AUTO)
+            ctx.wait(ra.LANE_AUTO)
+            for i, (d_o, off, n, want) in enumerate(issued):
+                assert_bit_exact(d_o.download(orc.RESULT_DTYPE, n), want[off:off + n], "chain_launches=%d, launch %d (%d rays)" % (chain, i, n))
+                d_o.free()
+            d_pool.free(); scene.destroy(); scene2.destroy(); env.destroy()
+
+
+def test_chained_launches_full_size(gpu_ctx, full):
+    """Twelve 1M-ray diffuse batches back to back (chained) and waits on single lanes in between: a lane's wait returns only when
+    its batch is complete, whoever traced it."""
+    blobs, sc = full["blobs"], full["sc"]
+    ref_prim = orc.traverse(blobs, full["primary"], env=sc["env"], threads=8)
+    bounce = synth.diffuse_bounce_rays(sc, full["primary"], ref_prim, 1 << 20)
+    want = orc.traverse(blobs, bounce, env=sc["env"], threads=8)
+    d_r = gpu_ctx.alloc(bounce.nbytes); d_r.upload(bounce)
+    outs = [gpu_ctx.alloc(len(bounce) * 16) for _ in range(12)]
+    for o in outs:
+        gpu_ctx.intersect_device(full["scene"], full["env"], d_r.ptr, o.ptr, len(bounce), lane=ra.LANE_AUTO)
+    gpu_ctx.wait((len(outs) - 1) % gpu_ctx.auto_lanes)          # the lane of the LAST batch: complete => every earlier batch of the chain is
+    for o in outs:
+        assert_bit_exact(o.download(orc.RESULT_DTYPE, len(bounce)), want, "chained 1M batches")
+        o.free()
+    gpu_ctx.wait(ra.LANE_AUTO)
+    d_r.free()
 
 
 def test_one_lane_from_two_caller_streams(gpu_ctx, small):
