@@ -25,9 +25,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# Deployment setting of the HIP runtime, read when it initialises: hardware queues for the engine's lanes (kernels of two HIP
-# streams that share a hardware queue do not overlap; the default of 4 leaves room for three lanes in rotation, 8 for six).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_MEASURED_GBS = 6290.0      # same guide: float4-copy ceiling

@@ -169,7 +169,12 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
  * under the next one's bulk — which is how the reference keeps its gpuSubmissionThreads queues busy
  * (RayAccelerator.cpp:711-717).  lane = RACC_HIP_LANE_AUTO rotates over the lanes, so a single-threaded caller that issues
  * batch after batch (stream = NULL) gets that overlap without managing lanes; racc_hip_wait(ctx, RACC_HIP_LANE_AUTO) or
- * racc_hip_synchronize then waits for all of them. */
+ * racc_hip_synchronize then waits for all of them.
+ * With stream = NULL the batch must be resident and final at the call, and — racc_hip_options::chain_launches, the default —
+ * launches are CHAINED: waves of the launches issued before may start on this batch at once and carry on through it, so that
+ * a sequence of batches runs like one long launch (20 batches of 1M rays back to back: 0.29 instead of 0.33 ms each).  The
+ * ray and result arrays of a batch then belong to the engine until racc_hip_wait (its lane, or RACC_HIP_LANE_AUTO) returns;
+ * a lane's wait returns when its batch is complete, whoever traced it.  A launch on a caller's stream is never chained. */
 int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
                               const void* d_rays, void* d_results, uint32_t count,
                               uint32_t lane, void* stream);

@@ -120,6 +120,8 @@ struct Lane {
     // slice's drain runs beside the next slice's bulk (each with half a grid), created on first use
     Lane* helper[3] = {nullptr, nullptr, nullptr};      // (the third only when the runtime has >= 8 hardware queues)
     uint32_t forceWavesPerSimd = 0;      // != 0: grid size of this (helper-rotated) launch
+    hipEvent_t chainKernelEnd = nullptr; // chained launches: recorded right after the lane's latest chained traversal kernel
+    bool chainKernelValid = false;
 };
 constexpr uint32_t kTimeRing = 256;
 
@@ -340,7 +342,7 @@ struct Variant {
     int reserved = 0;          // LDS levels the kernel keeps for itself (V5: the sentinel; V6: sentinel + trash level)
     int stagePerWave = 0;      // bytes of LDS-DMA stage per wave (V6 COOP)
     bool wide = false;         // traverses the 4-wide device format (V9)
-    bool chains = false;       // its waves can move on to the next launch of a chain (V8)
+    void (*kernelChained)(const TraverseArgs) = nullptr;      // the instantiation whose waves can move on to the next launch of a chain (V8)
     int stackLevels() const { return (ldsLevels > 32 ? ldsLevels - (kRecFields + 1) : ldsLevels / slots) - reserved; }   // V3 rows fold the record words into ldsLevels
 };
 // kernel_variant n selects kVariants[n-1]; 0 selects the default (V8).  LDS per workgroup = cacheNodes*64 + ldsLevels*block*4
@@ -392,10 +394,10 @@ const Variant kVariants[] = {
     {256, 10, 0, RACC_X(traverseKernelV7<256, 9, false>), false, true, 1, 2, 4 * 1040},           // 38: V7: V6 as refill-loop around work-loop (no per-iteration register copies), thin waves fetch per lane
     {256, 10, 0, RACC_X(traverseKernelV7<256, 9, true>), false, true, 1, 2, 4 * 1040},            // 39: variant 38 + statistics (debug)
     {256, 14, 0, RACC_X(traverseKernelV7<256, 13, false>), false, true, 1, 2, 4 * 1040},          // 40: V7, 12-entry LDS stack (5 workgroups per CU)
-    {256, 10, 0, traverseKernelV8<256, 9, false>, false, true, 1, 2, 4 * 1040, false, true},           // 41: V8 with an 8-entry LDS stack (exercises the DEEP door and the spill: 2.6 % of the bench rays)
-    {256, 14, 0, traverseKernelV8<256, 13, true>, false, true, 1, 2, 4 * 1040, false, true},           // 42: variant 43 + statistics (debug; only the C++ parts count: refills, rays loaded, waves)
-    {256, 14, 0, traverseKernelV8<256, 13, false>, false, true, 1, 2, 4 * 1040, false, true},          // 43: V8, 12-entry LDS stack: the default
-    {256, 14, 0, traverseKernelV8<256, 13, false, false>, false, false, 1, 2, 4 * 1040, false, true},  // 44: variant 43 with the probe-image lookup in its own epilogue (no envShadeKernel launch)
+    {256, 10, 0, traverseKernelV8<256, 9, false>, false, true, 1, 2, 4 * 1040, false, traverseKernelV8<256, 9, false, true, true>},           // 41: V8 with an 8-entry LDS stack (exercises the DEEP door and the spill: 2.6 % of the bench rays)
+    {256, 14, 0, traverseKernelV8<256, 13, true>, false, true, 1, 2, 4 * 1040, false, nullptr},           // 42: variant 43 + statistics (debug; only the C++ parts count: refills, rays loaded, waves)
+    {256, 14, 0, traverseKernelV8<256, 13, false>, false, true, 1, 2, 4 * 1040, false, traverseKernelV8<256, 13, false, true, true>},          // 43: V8, 12-entry LDS stack: the default
+    {256, 14, 0, traverseKernelV8<256, 13, false, false>, false, false, 1, 2, 4 * 1040, false, traverseKernelV8<256, 13, false, false, true>},  // 44: variant 43 with the probe-image lookup in its own epilogue (no envShadeKernel launch)
     {256, 19, 0, traverseKernelV9<256, 19, false, true>, false, true, 1, 1, 8 * 1040, true},    // 45: V9 (4-wide nodes, hot loop in assembly), 18-entry LDS stack: 3 workgroups per CU
     {256, 7, 0, traverseKernelV9<256, 7, false, false>, false, true, 1, 1, 8 * 1040, true},     // 46: V9 in plain C++, 6-entry LDS stack + spill: 4 workgroups per CU (exercises the spill)
     {256, 19, 0, traverseKernelV9<256, 19, true, false>, false, true, 1, 1, 8 * 1040, true},    // 47: V9 in plain C++ + statistics (debug)
@@ -436,7 +438,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     // diffuse batches (tools/gpu_overlap.py): 0.378 ms per batch one at a time; back to back over 3 lanes 0.294 with full
     // grids, 0.271 with 3 waves per SIMD each, 0.266 with 2 (0.33 / 0.28 with four / five lanes in rotation: three it is).
     // ---- chained launches: is the launch issued just before this one (any lane) still running on the same scene?
-    const bool chain = mayChain && v.chains && ctx->chainEnabled && ctx->chainDev != nullptr && count < 0x80000000u;      // (bit 31 of a ray index tags the batch)
+    const bool chain = mayChain && v.kernelChained && ctx->chainEnabled && ctx->chainDev != nullptr && count < 0x80000000u;      // (bit 31 of a ray index tags the batch)
     std::unique_lock<std::mutex> chainGuard(ctx->chainMutex, std::defer_lock);
     uint32_t chainIdx = 0;
     int chainPred = -1;
@@ -453,7 +455,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
             HIP_TRY(hipMemset(ctx->chainDev, 0, sizeof(ChainDesc) * racc_hip_ctx::kChainRing), "hipMemset(chain ring)");
             ctx->chainLast.valid = false;
         }
-        if (ctx->chainLast.valid && ctx->chainLast.scene == scene && ctx->chainLast.env == env && ctx->chainLast.kernel == reinterpret_cast<const void*>(v.kernel) &&
+        if (ctx->chainLast.valid && ctx->chainLast.scene == scene && ctx->chainLast.env == env && ctx->chainLast.kernel == reinterpret_cast<const void*>(v.kernelChained) &&
             hipEventQuery(ctx->chainDone[ctx->chainLast.idx]) == hipErrorNotReady)
             chainPred = int(ctx->chainLast.idx);
         (void)hipGetLastError();      // hipErrorNotReady is not an error
@@ -524,7 +526,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     if (lane.everLaunched && lane.lastStream != stream) HIP_TRY(hipStreamWaitEvent(stream, lane.done, 0), "hipStreamWaitEvent(lane)");
     const bool timed = ctx->opts.time_kernels != 0u && !lane.ring.empty();
     if (timed) HIP_TRY(hipEventRecord(lane.ring[2 * lane.ringHead], stream), "hipEventRecord");
-    hipLaunchKernelGGL(v.kernel, dim3(blocks), dim3(v.block), 0, stream, a);
+    hipLaunchKernelGGL(chain ? v.kernelChained : v.kernel, dim3(blocks), dim3(v.block), 0, stream, a);
     HIP_TRY(hipGetLastError(), "launch traverseKernel");
     if (timed) {
         HIP_TRY(hipEventRecord(lane.ring[2 * lane.ringHead + 1], stream), "hipEventRecord");
@@ -537,10 +539,20 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
         hipLaunchKernelGGL(chainPublishKernel, dim3(1), dim3(1), 0, ctx->chainStream, ctx->chainDev, chainIdx, a.rays, a.results, a.cursor, count,
                            blocks * uint32_t(v.block / 64) * a.chunk, chainPred);
         HIP_TRY(hipGetLastError(), "launch chainPublishKernel");
-        if (chainPred >= 0) HIP_TRY(hipStreamWaitEvent(stream, ctx->chainDone[chainPred], 0), "hipStreamWaitEvent(chain)");
+        // Every kernel issued before this one may have worked on this batch.  Those on this stream have ended when this one starts;
+        // of every other lane the latest one is waited for (the earlier ones on its stream ended before it): two waits with three
+        // lanes, and no chain of events from launch to launch that would serialise the ends of a long sequence.
+        if (!lane.chainKernelEnd) HIP_TRY(hipEventCreateWithFlags(&lane.chainKernelEnd, hipEventDisableTiming), "hipEventCreate");
+        HIP_TRY(hipEventRecord(lane.chainKernelEnd, stream), "hipEventRecord(chain kernel)");
+        lane.chainKernelValid = true;
+        if (chainPred >= 0)
+            for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
+                Lane& other = ctx->lanes[i];
+                if (&other != &lane && other.chainKernelValid) HIP_TRY(hipStreamWaitEvent(stream, other.chainKernelEnd, 0), "hipStreamWaitEvent(chain)");
+            }
         HIP_TRY(hipEventRecord(ctx->chainDone[chainIdx], stream), "hipEventRecord(chain)");      // = this kernel and every one before it in the chain has ended
         ctx->chainUsed[chainIdx] = true;
-        ctx->chainLast.scene = scene; ctx->chainLast.env = env; ctx->chainLast.kernel = reinterpret_cast<const void*>(v.kernel);
+        ctx->chainLast.scene = scene; ctx->chainLast.env = env; ctx->chainLast.kernel = reinterpret_cast<const void*>(v.kernelChained);
         ctx->chainLast.idx = chainIdx; ctx->chainLast.valid = true;
         ++ctx->chainHead;
     }
@@ -597,6 +609,7 @@ void freeLane(Lane& l) {
     for (hipEvent_t ev : l.pipeEvents) hipEventDestroy(ev);
     for (hipEvent_t ev : l.ring) if (ev) hipEventDestroy(ev);
     if (l.done) hipEventDestroy(l.done);
+    if (l.chainKernelEnd) hipEventDestroy(l.chainKernelEnd);
     if (l.copyIn) hipStreamDestroy(l.copyIn);
     if (l.copyOut) hipStreamDestroy(l.copyOut);
     if (l.cursor) hipFree(l.cursor);
