@@ -120,7 +120,8 @@ struct Lane {
     // slice's drain runs beside the next slice's bulk (each with half a grid), created on first use
     Lane* helper[3] = {nullptr, nullptr, nullptr};      // (the third only when the runtime has >= 8 hardware queues)
     uint32_t forceWavesPerSimd = 0;      // != 0: grid size of this (helper-rotated) launch
-    hipEvent_t chainKernelEnd = nullptr; // chained launches: recorded right after the lane's latest chained traversal kernel
+    hipEvent_t chainKernelEnd = nullptr; // chained launches: recorded right after the lane's latest chained traversal kernel ...
+    hipEvent_t chainKernelEndEv = nullptr;   // ... or, with time_kernels, that launch's timing end event (not owned)
     bool chainKernelValid = false;
 };
 constexpr uint32_t kTimeRing = 256;
@@ -144,11 +145,9 @@ struct racc_hip_ctx {
     ChainDesc* chainDev = nullptr;       // the ring of descriptors (device memory, written by chainPublishKernel)
     hipStream_t chainStream = nullptr;   // control stream of the publish kernels
     uint32_t* chainCursors = nullptr;    // device: kChainRing x 16 words (cursor at word 0), all zero between ring laps
-    hipEvent_t chainDone[kChainRing] = {};   // recorded right after each chained kernel
-    bool chainUsed[kChainRing] = {};
     uint32_t chainHead = 0;              // launches so far
     std::mutex chainMutex;
-    struct { const racc_hip_scene* scene = nullptr; const racc_hip_env* env = nullptr; const void* kernel = nullptr; uint32_t idx = 0; bool valid = false; } chainLast;
+    struct { const racc_hip_scene* scene = nullptr; const racc_hip_env* env = nullptr; const void* kernel = nullptr; uint32_t idx = 0; Lane* lane = nullptr; bool valid = false; } chainLast;
     bool chainEnabled = true;            // RACC_CHAIN=0 switches it off
     uint32_t maxIters = 1u << 24;        // RACC_MAX_ITERS overrides (tests)
 };
@@ -446,8 +445,8 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
         chainGuard.lock();
         chainIdx = ctx->chainHead % racc_hip_ctx::kChainRing;
         if (chainIdx == 0 && ctx->chainHead != 0) {      // a lap of the ring: every cursor word must be zero again before it is handed out
-            for (uint32_t i = 0; i < racc_hip_ctx::kChainRing; ++i)
-                if (ctx->chainUsed[i]) { HIP_TRY(hipEventSynchronize(ctx->chainDone[i]), "hipEventSynchronize(chain)"); ctx->chainUsed[i] = false; }
+            for (uint32_t i = 0; i < ctx->opts.lanes; ++i)      // (chained launches only ever go to the lanes' own streams)
+                if (ctx->lanes[i].everLaunched) HIP_TRY(hipEventSynchronize(ctx->lanes[i].done), "hipEventSynchronize(chain lap)");
             HIP_TRY(hipStreamSynchronize(ctx->chainStream), "hipStreamSynchronize(chain)");
             HIP_TRY(hipMemset(ctx->chainCursors, 0, size_t(racc_hip_ctx::kChainRing) * 64), "hipMemset(chain cursors)");
             // ... and no descriptor may keep a link of the lap before: a kernel can look at its own descriptor before the publish
@@ -456,7 +455,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
             ctx->chainLast.valid = false;
         }
         if (ctx->chainLast.valid && ctx->chainLast.scene == scene && ctx->chainLast.env == env && ctx->chainLast.kernel == reinterpret_cast<const void*>(v.kernelChained) &&
-            hipEventQuery(ctx->chainDone[ctx->chainLast.idx]) == hipErrorNotReady)
+            ctx->chainLast.lane->everLaunched && hipEventQuery(ctx->chainLast.lane->done) == hipErrorNotReady)      // (`done`: its kernel, every kernel before it, its miss shading)
             chainPred = int(ctx->chainLast.idx);
         (void)hipGetLastError();      // hipErrorNotReady is not an error
     }
@@ -542,18 +541,20 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
         // Every kernel issued before this one may have worked on this batch.  Those on this stream have ended when this one starts;
         // of every other lane the latest one is waited for (the earlier ones on its stream ended before it): two waits with three
         // lanes, and no chain of events from launch to launch that would serialise the ends of a long sequence.
-        if (!lane.chainKernelEnd) HIP_TRY(hipEventCreateWithFlags(&lane.chainKernelEnd, hipEventDisableTiming), "hipEventCreate");
-        HIP_TRY(hipEventRecord(lane.chainKernelEnd, stream), "hipEventRecord(chain kernel)");
+        if (timed) lane.chainKernelEndEv = lane.ring[2 * ((lane.ringHead + kTimeRing - 1u) % kTimeRing) + 1];      // the timing pair's end event serves
+        else {
+            if (!lane.chainKernelEnd) HIP_TRY(hipEventCreateWithFlags(&lane.chainKernelEnd, hipEventDisableTiming), "hipEventCreate");
+            HIP_TRY(hipEventRecord(lane.chainKernelEnd, stream), "hipEventRecord(chain kernel)");
+            lane.chainKernelEndEv = lane.chainKernelEnd;
+        }
         lane.chainKernelValid = true;
         if (chainPred >= 0)
             for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
                 Lane& other = ctx->lanes[i];
-                if (&other != &lane && other.chainKernelValid) HIP_TRY(hipStreamWaitEvent(stream, other.chainKernelEnd, 0), "hipStreamWaitEvent(chain)");
+                if (&other != &lane && other.chainKernelValid) HIP_TRY(hipStreamWaitEvent(stream, other.chainKernelEndEv, 0), "hipStreamWaitEvent(chain)");
             }
-        HIP_TRY(hipEventRecord(ctx->chainDone[chainIdx], stream), "hipEventRecord(chain)");      // = this kernel and every one before it in the chain has ended
-        ctx->chainUsed[chainIdx] = true;
         ctx->chainLast.scene = scene; ctx->chainLast.env = env; ctx->chainLast.kernel = reinterpret_cast<const void*>(v.kernelChained);
-        ctx->chainLast.idx = chainIdx; ctx->chainLast.valid = true;
+        ctx->chainLast.idx = chainIdx; ctx->chainLast.lane = &lane; ctx->chainLast.valid = true;
         ++ctx->chainHead;
     }
     lane.pendingEnv = v.deferEnv && env != nullptr;
@@ -758,7 +759,6 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
         }
         if (e1 == hipSuccess) e1 = hipMalloc(reinterpret_cast<void**>(&ctx->chainCursors), size_t(racc_hip_ctx::kChainRing) * 64);
         if (e1 == hipSuccess) e1 = hipMemset(ctx->chainCursors, 0, size_t(racc_hip_ctx::kChainRing) * 64);
-        for (uint32_t i = 0; i < racc_hip_ctx::kChainRing && e1 == hipSuccess; ++i) e1 = hipEventCreateWithFlags(&ctx->chainDone[i], hipEventDisableTiming);
         if (e1 != hipSuccess) { racc_hip_destroy(ctx); return fail(RACC_HIP_ERR_DEVICE, "chain ring", e1); }
     }
     *out = ctx;
@@ -773,7 +773,6 @@ int racc_hip_destroy(racc_hip_ctx* ctx) {
     if (ctx->chainDev) hipFree(ctx->chainDev);
     if (ctx->chainStream) hipStreamDestroy(ctx->chainStream);
     if (ctx->chainCursors) hipFree(ctx->chainCursors);
-    for (hipEvent_t ev : ctx->chainDone) if (ev) hipEventDestroy(ev);
     for (Lane& l : ctx->lanes) freeLane(l);
     delete ctx;
     return RACC_HIP_OK;
