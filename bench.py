@@ -8,8 +8,10 @@ N=8, weak scaling, no data-path collective — rays never interact).  Inputs are
 in HBM before the timed region.  The K steps are issued the way a caller of the C-ABI
 issues batch after batch: racc_hip_intersect_device(lane = RACC_HIP_LANE_AUTO), i.e. the
 engine rotates them over its lanes (≙ the reference's gpuSubmissionThreads queues,
-RayAccelerator.cpp:711-717) and one step's drain runs under the next one's bulk; the
-timed region ends when every step's results are in HBM.  Output: ONE JSON line on rank 0.
+RayAccelerator.cpp:711-717), and chains them: waves that run out of rays in one step's
+batch go on with the next step's (include/racc_hip.h, chain_launches), so no step's drain
+leaves the machine empty; every step has its own result array; the timed region ends when
+every step's results are in HBM.  Output: ONE JSON line on rank 0.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
