@@ -152,7 +152,7 @@ def main():
     d_rays = torch.from_numpy(bounce.view(np.float32).reshape(n, 8).copy()).cuda()
     # One result array per batch issued between two waits: chained launches (racc_hip_options::chain_launches, the default) keep a
     # batch's arrays until the wait returns.  16 MiB each: 3.1 GiB for the default 200 steps.  The ray array is read-only and shared.
-    outs = [torch.zeros((n, 4), dtype=torch.float32, device="cuda") for _ in range(max(args.steps, args.warmup, lanes, 2))]
+    outs = [torch.zeros((n, 4), dtype=torch.float32, device="cuda") for _ in range(min(max(args.steps, args.warmup, lanes, 2), 1024))]      # (beyond 1024 steps arrays repeat: every step writes the same bits)
     d_out = outs[0]
     torch.cuda.synchronize()
 
