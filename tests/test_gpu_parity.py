@@ -484,6 +484,40 @@ def test_chained_launches(small_scene, small_host, small):
             d_pool.free(); scene.destroy(); scene2.destroy(); env.destroy()
 
 
+def test_chained_launches_from_three_threads(gpu_ctx, small):
+    """Three host threads issue chained batches on one context at once and wait on their own: the chain is shared, every batch
+    bit-exact."""
+    batches = _batches(small)
+    pool = np.concatenate([batches["primary"], batches["diffuse"]])
+    ref = orc.traverse(small["blobs"], pool, env=small["sc"]["env"])
+    d_pool = gpu_ctx.alloc(pool.nbytes); d_pool.upload(pool)
+    errs = []
+
+    def work(seed):
+        rng = np.random.default_rng(seed)
+        for _ in range(4):
+            outs = []
+            for _ in range(40):
+                n = int(rng.choice([1, 64, 1000, 20000, int(rng.integers(1, len(pool)))]))
+                off = int(rng.integers(0, len(pool) - n + 1))
+                d_o = gpu_ctx.alloc(n * 16)
+                gpu_ctx.intersect_device(small["scene"], small["env"], d_pool.ptr + off * 32, d_o.ptr, n, lane=ra.LANE_AUTO)
+                outs.append((d_o, off, n))
+            gpu_ctx.wait(ra.LANE_AUTO)
+            for d_o, off, n in outs:
+                try:
+                    assert_bit_exact(d_o.download(orc.RESULT_DTYPE, n), ref[off:off + n], "thread %d" % seed)
+                except AssertionError as e:
+                    errs.append(str(e)[:200])
+                d_o.free()
+
+    ts = [threading.Thread(target=work, args=(s,)) for s in (1, 2, 3)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    d_pool.free()
+    assert not errs, errs[:3]
+
+
 def test_chained_launches_full_size(gpu_ctx, full):
     """Twelve 1M-ray diffuse batches back to back (chained) and waits on single lanes in between: a lane's wait returns only when
     its batch is complete, whoever traced it."""
