@@ -99,9 +99,9 @@ typedef struct racc_hip_launch_info {
 
 const char* racc_hip_last_error(void);             /* thread-local, never NULL */
 const char* racc_hip_version(void);
-/* The lanes a context has (options.lanes, or the default: 4; 6 when the HIP runtime was given >= 8 hardware queues,
- * GPU_MAX_HW_QUEUES) and how many of them RACC_HIP_LANE_AUTO rotates over (3 or 6: kernels of two streams that share a
- * hardware queue do not overlap; RACC_AUTO_LANES overrides).  A caller that rotates result buffers needs at least
+/* The lanes a context has (options.lanes, or the default: 4; without chained launches 6 when the HIP runtime was given >= 8
+ * hardware queues, GPU_MAX_HW_QUEUES) and how many of them RACC_HIP_LANE_AUTO rotates over (3; without chained launches 6 in
+ * that case: kernels of two streams that share a hardware queue do not overlap; RACC_AUTO_LANES overrides).  A caller that rotates result buffers needs at least
  * `auto_lanes` of them.  Either pointer may be NULL. */
 int racc_hip_lane_count(const racc_hip_ctx* ctx, uint32_t* lanes, uint32_t* auto_lanes);
 
