@@ -59,7 +59,7 @@ typedef struct racc_hip_options {
     uint32_t inner_reps;       /* V2 kernels: inner steps any other wave runs per scheduling iteration; 0 => default (3) */
     uint32_t coop_same_pct;    /* V7 kernels: inner steps fetch nodes quad-cooperatively through LDS-DMA while fewer than this
                                   percentage of the inner lanes hold the same node as their quad neighbour (divergent waves);
-                                  0 => default (50), > 100 => never, 100 => always */
+                                  0 => default (20), > 100 => never, 100 => always */
     uint32_t time_kernels;     /* != 0: an event pair around every traversal kernel (racc_hip_read_kernel_times); costs two
                                   hipEventRecord per launch, so off by default */
     uint32_t drain_prefetch;   /* 1: thin waves of an exhausted batch touch both children's records as soon as a node's child refs

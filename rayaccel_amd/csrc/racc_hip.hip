@@ -17,7 +17,7 @@
 //   * launches of different lanes (HIP stream + ray cursor + spill area each) overlap: one's drain runs beside the next
 //     one's bulk.
 // The shipped kernel, traverseKernelV8 (hot loop in hand-scheduled assembly), is in racc_kernel_v8.inc; the seven earlier
-// generations are in racc_kernels_experimental.inc and exist only in a `make EXPERIMENTAL=1` build.
+// generations are in tools/experimental/racc_kernels_experimental.inc and exist only in a `make EXPERIMENTAL=1` build.
 // Arithmetic is IEEE binary32 with explicit fmaf only (built with -ffp-contract=off, no fast-math), the same evaluation
 // order as oracle/racc_oracle.c, so primId/t/u/v are bit-identical to the CPU restatement for every finite ray.  The
 // traversal ORDER is the reference's (nearer child first, far child pushed only if both hit, pairs of a leaf in order),
@@ -54,7 +54,7 @@ namespace {
 #include "racc_kernel_v9.inc"
 
 #ifdef RACC_EXPERIMENTAL
-#include "racc_kernels_experimental.inc"      // V1..V7: earlier generations and ablations, `make EXPERIMENTAL=1`
+#include "racc_kernels_experimental.inc"      // V1..V7: earlier generations and ablations, tools/experimental/, `make EXPERIMENTAL=1`
 #endif
 
 // ------------------------------------------------------------------------------------------ host side
@@ -333,6 +333,7 @@ constexpr int kRecFields = 20;     // (V3's LDS record, racc_kernels_experimenta
 #endif
 
 struct Variant {
+    int id;                    // the racc_hip_options::kernel_variant number that selects this row
     int block, ldsLevels, cacheNodes;
     void (*kernel)(const TraverseArgs);
     bool noSpill = false;      // kernel has no global spill path: only valid while tree height <= ldsLevels
@@ -344,79 +345,40 @@ struct Variant {
     void (*kernelChained)(const TraverseArgs) = nullptr;      // the instantiation whose waves can move on to the next launch of a chain (V8)
     int stackLevels() const { return (ldsLevels > 32 ? ldsLevels - (kRecFields + 1) : ldsLevels / slots) - reserved; }   // V3 rows fold the record words into ldsLevels
 };
-// kernel_variant n selects kVariants[n-1]; 0 selects the default (V8).  LDS per workgroup = cacheNodes*64 + ldsLevels*block*4
-// (+ the LDS-DMA stage).  Rows 1-40 are earlier generations and ablations: their kernels exist only in a `make EXPERIMENTAL=1`
-// build (racc_kernels_experimental.inc); otherwise racc_hip_create refuses those numbers.
-#ifdef RACC_EXPERIMENTAL
-#define RACC_X(...) __VA_ARGS__
-#else
-#define RACC_X(...) nullptr
-#endif
+// kernel_variant n selects the row with id n; 0 selects the default (V8).  LDS per workgroup = cacheNodes*64 + ldsLevels*block*4
+// (+ the LDS-DMA stage).  Ids 1-40 are earlier generations and ablations: they live outside the product tree
+// (tools/experimental/) and exist only in a `make EXPERIMENTAL=1` build; otherwise racc_hip_create refuses those numbers.
 const Variant kVariants[] = {
-    {256, 16, 0, RACC_X(traverseKernel<256, 16, 0>)},          // 1: no node cache, 16 KiB/WG, up to 8 WG/CU
-    {1024, 12, 1792, RACC_X(traverseKernel<1024, 12, 1792>)},  // 2: 160 KiB: 112 KiB cache + 48 KiB stacks, 1 WG/CU (4 waves/SIMD)
-    {1024, 16, 1536, RACC_X(traverseKernel<1024, 16, 1536>)},  // 3: 160 KiB: 96 + 64
-    {512, 16, 2048, RACC_X(traverseKernel<512, 16, 2048>)},    // 4: 160 KiB: 128 + 32, 1 WG/CU (2 waves/SIMD)
-    {512, 8, 960, RACC_X(traverseKernel<512, 8, 960>)},        // 5: 76 KiB: 60 + 16, 2 WG/CU
-    {256, 8, 448, RACC_X(traverseKernel<256, 8, 448>)},        // 6: 36 KiB: 28 + 8, 4 WG/CU
-    {1024, 12, 1024, RACC_X(traverseKernel<1024, 12, 1024>)},  // 7: 112 KiB: 64 + 48
-    {512, 12, 1024, RACC_X(traverseKernel<512, 12, 1024>)},    // 8: 88 KiB: 64 + 24, 1 WG/CU
-    {256, 16, 0, RACC_X(traverseKernel<256, 16, 0, true>)},    // 9: variant 1 + scheduling statistics (debug)
-    {256, 32, 0, RACC_X(traverseKernelV2<256, 32, false, false>), true, true},   // 10: V2, 32 LDS levels, no spill path (height <= 32)
-    {256, 16, 0, RACC_X(traverseKernelV2<256, 16, true, false>), false, true},    // 11: V2, 16 LDS levels + global spill (any height)
-    {256, 32, 0, RACC_X(traverseKernelV2<256, 32, false, true>), true, true},    // 12: variant 10 + statistics (debug)
-    {256, 24, 0, RACC_X(traverseKernelV2<256, 24, true, false>), false, true},    // 13: V2, 24 LDS levels + spill
-    {256, 32, 0, RACC_X(traverseKernelV2<256, 32, false, false, false, false>), true, true},   // 14: V2 ablation: global loads, no top-of-stack register
-    {256, 32, 0, RACC_X(traverseKernelV2<256, 32, false, false, true, false>), true, true},    // 15: V2 ablation: buffer loads only
-    {256, 32, 0, RACC_X(traverseKernelV2<256, 32, false, false, false, true>), true, true},    // 16: V2 ablation: top-of-stack register only
-    {256, 16, 0, RACC_X(traverseKernelV2<256, 16, true, false, false, false>), false, true},          // 17: V2 ablation: 16 levels + spill, neither
-    {512, 16 + kRecFields + 1, 0, RACC_X(traverseKernelV3<8, 16, true, false>), false, true},      // 18: V3, 8-wave workgroups (2 per CU)
-    {1024, 16 + kRecFields + 1, 0, RACC_X(traverseKernelV3<16, 16, true, false>), false, true},    // 19: V3, 16-wave workgroups (1 per CU)
-    {256, 16 + kRecFields + 1, 0, RACC_X(traverseKernelV3<4, 16, true, false>), false, true},      // 20: V3, 4-wave workgroups (4 per CU)
-    {512, 16 + kRecFields + 1, 0, RACC_X(traverseKernelV3<8, 16, true, true>), false, true},       // 21: variant 18 + statistics (debug)
-    {256, 26, 0, RACC_X(traverseKernelV2<256, 26, false, false, false, false>), true, true},       // 22: V2, 26 LDS levels, no spill path (26 KiB: 6 WG/CU)
-    {256, 28, 0, RACC_X(traverseKernelV2<256, 28, false, false, false, false>), true, true},       // 23: V2, 28 LDS levels, no spill path (28 KiB: 5 WG/CU)
-    {256, 30, 0, RACC_X(traverseKernelV2<256, 30, false, false, false, false>), true, true},       // 24: V2, 30 LDS levels, no spill path
-    {256, 26, 0, RACC_X(traverseKernelV2<256, 26, false, false, false, false, true>), true, true}, // 25: variant 22 + per-XCD ray queues (measured slower: DESIGN.md §3)
-    {256, 26, 0, RACC_X(traverseKernelV2<256, 26, false, true, false, false, false>), true, true}, // 26: variant 22 + statistics (debug)
-    {256, 26, 0, RACC_X(traverseKernelV2<256, 26, false, false, false, false, false, true>), true, true}, // 27: variant 22 with the node records transposed to SoA planes (ablation: DESIGN.md §2)
-    {256, 26, 0, RACC_X(traverseKernelV2<256, 26, false, false, false, false, false, false, true>), true, true}, // 28: variant 22 + touch loads of both children in thin waves
-    {256, 26, 0, RACC_X(traverseKernelV4<256, 13, false>), false, true, 2},   // 29: V4, two ray slots per lane, 13 LDS levels each + spill
-    {256, 26, 0, RACC_X(traverseKernelV4<256, 13, true>), false, true, 2},    // 30: variant 29 + statistics (debug)
-    {256, 26, 0, RACC_X(traverseKernelV5<256, 26, false>), true, true, 1, 1},   // 31: V5 (straight-line steps, sentinel stack), 26 LDS levels: height <= 25
-    {256, 32, 0, RACC_X(traverseKernelV5<256, 32, false>), true, true, 1, 1},   // 32: V5, 32 LDS levels: height <= 31
-    {256, 26, 0, RACC_X(traverseKernelV5<256, 26, true>), true, true, 1, 1},    // 33: variant 31 + statistics (debug)
-    {256, 10, 0, RACC_X(traverseKernelV6<256, 9, false, true>), false, true, 1, 2, 4 * 1040},     // 34: V6: 8-entry LDS stack + spill, quad-cooperative LDS-DMA node fetch
-    {256, 10, 0, RACC_X(traverseKernelV6<256, 9, false, false>), false, true, 1, 2},              // 35: V6 stack, per-lane node loads (A/B of the fetch)
-    {256, 14, 0, RACC_X(traverseKernelV6<256, 13, false, true>), false, true, 1, 2, 4 * 1040},    // 36: V6, 12-entry LDS stack (5 workgroups per CU)
-    {256, 10, 0, RACC_X(traverseKernelV6<256, 9, true, true>), false, true, 1, 2, 4 * 1040},      // 37: variant 34 + statistics (debug)
-    {256, 10, 0, RACC_X(traverseKernelV7<256, 9, false>), false, true, 1, 2, 4 * 1040},           // 38: V7: V6 as refill-loop around work-loop (no per-iteration register copies), thin waves fetch per lane
-    {256, 10, 0, RACC_X(traverseKernelV7<256, 9, true>), false, true, 1, 2, 4 * 1040},            // 39: variant 38 + statistics (debug)
-    {256, 14, 0, RACC_X(traverseKernelV7<256, 13, false>), false, true, 1, 2, 4 * 1040},          // 40: V7, 12-entry LDS stack (5 workgroups per CU)
-    {256, 10, 0, traverseKernelV8<256, 9, false>, false, true, 1, 2, 4 * 1040, false, traverseKernelV8<256, 9, false, true, true>},           // 41: V8 with an 8-entry LDS stack (exercises the DEEP door and the spill: 2.6 % of the bench rays)
-    {256, 14, 0, traverseKernelV8<256, 13, true>, false, true, 1, 2, 4 * 1040, false, nullptr},           // 42: variant 43 + statistics (debug; only the C++ parts count: refills, rays loaded, waves)
-    {256, 14, 0, traverseKernelV8<256, 13, false>, false, true, 1, 2, 4 * 1040, false, traverseKernelV8<256, 13, false, true, true>},          // 43: V8, 12-entry LDS stack: the default
-    {256, 14, 0, traverseKernelV8<256, 13, false, false>, false, false, 1, 2, 4 * 1040, false, traverseKernelV8<256, 13, false, false, true>},  // 44: variant 43 with the probe-image lookup in its own epilogue (no envShadeKernel launch)
-    {256, 19, 0, traverseKernelV9<256, 19, false, true>, false, true, 1, 1, 8 * 1040, true},    // 45: V9 (4-wide nodes, hot loop in assembly), 18-entry LDS stack: 3 workgroups per CU
-    {256, 7, 0, traverseKernelV9<256, 7, false, false>, false, true, 1, 1, 8 * 1040, true},     // 46: V9 in plain C++, 6-entry LDS stack + spill: 4 workgroups per CU (exercises the spill)
-    {256, 19, 0, traverseKernelV9<256, 19, true, false>, false, true, 1, 1, 8 * 1040, true},    // 47: V9 in plain C++ + statistics (debug)
-    {256, 19, 0, traverseKernelV9<256, 19, false, false>, false, true, 1, 1, 8 * 1040, true},   // 48: V9 in plain C++ (A/B of the assembly block)
-    {256, 8, 0, traverseKernelV9<256, 8, false, true>, false, true, 1, 1, 8 * 1040, true},      // 49: variant 45 with a 7-entry LDS stack (exercises the DEEP door and the spill)
+#ifdef RACC_EXPERIMENTAL
+#include "racc_variants_experimental.inc"
+#endif
+    {41, 256, 10, 0, traverseKernelV8<256, 9, false>, false, true, 1, 2, 4 * 1040, false, traverseKernelV8<256, 9, false, true, true>},           // 41: V8 with an 8-entry LDS stack (exercises the DEEP door and the spill: 2.6 % of the bench rays)
+    {42, 256, 14, 0, traverseKernelV8<256, 13, true>, false, true, 1, 2, 4 * 1040, false, nullptr},           // 42: variant 43 + statistics (debug; only the C++ parts count: refills, rays loaded, waves)
+    {43, 256, 14, 0, traverseKernelV8<256, 13, false>, false, true, 1, 2, 4 * 1040, false, traverseKernelV8<256, 13, false, true, true>},          // 43: V8, 12-entry LDS stack: the default
+    {44, 256, 14, 0, traverseKernelV8<256, 13, false, false>, false, false, 1, 2, 4 * 1040, false, traverseKernelV8<256, 13, false, false, true>},  // 44: variant 43 with the probe-image lookup in its own epilogue (no envShadeKernel launch)
+    {45, 256, 19, 0, traverseKernelV9<256, 19, false, true>, false, true, 1, 1, 8 * 1040, true},    // 45: V9 (4-wide nodes, hot loop in assembly), 18-entry LDS stack: 3 workgroups per CU
+    {46, 256, 7, 0, traverseKernelV9<256, 7, false, false>, false, true, 1, 1, 8 * 1040, true},     // 46: V9 in plain C++, 6-entry LDS stack + spill: 4 workgroups per CU (exercises the spill)
+    {47, 256, 19, 0, traverseKernelV9<256, 19, true, false>, false, true, 1, 1, 8 * 1040, true},    // 47: V9 in plain C++ + statistics (debug)
+    {48, 256, 19, 0, traverseKernelV9<256, 19, false, false>, false, true, 1, 1, 8 * 1040, true},   // 48: V9 in plain C++ (A/B of the assembly block)
+    {49, 256, 8, 0, traverseKernelV9<256, 8, false, true>, false, true, 1, 1, 8 * 1040, true},      // 49: variant 45 with a 7-entry LDS stack (exercises the DEEP door and the spill)
 };
-constexpr int kNumVariants = int(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kSoaVariant = 27;
 constexpr int kWideVariant = 45;
 constexpr int kDefaultVariant = 43;   // V8, 12-entry LDS stack + global spill (any tree height)
 constexpr int kSpillFallback = kDefaultVariant;    // used when a tree is taller than an LDS-only variant's stack
 constexpr uint32_t kLdsPerCU = 160u * 1024u;
 
+const Variant* variantById(uint32_t id) {
+    for (const Variant& v : kVariants) if (uint32_t(v.id) == id && v.kernel) return &v;
+    return nullptr;
+}
+
 // kernel_variant 0 (default): V8 with a 12-entry LDS stack.  On battlefield-synth 99.99 % of the rays never go deeper
 // (mean 4.7, max 15); the rest of any tree's height lives in the global spill.
 const Variant& pickVariant(const racc_hip_ctx* ctx, uint32_t treeHeight) {
     (void)treeHeight;
-    const uint32_t v = ctx->opts.kernel_variant;
-    if (v >= 1 && v <= uint32_t(kNumVariants) && kVariants[v - 1].kernel) return kVariants[v - 1];
-    return kVariants[kDefaultVariant - 1];
+    if (const Variant* v = variantById(ctx->opts.kernel_variant)) return *v;
+    return *variantById(kDefaultVariant);
 }
 
 // mayChain: the batch is resident and final NOW (a device-resident batch issued on one of the engine's own streams), so waves of
@@ -425,8 +387,8 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
                    const void* dRays, void* dResults, uint32_t count, bool mayChain = false) {
     if (!count) return RACC_HIP_OK;
     const Variant* vp = &pickVariant(ctx, scene->info.inner_height);
-    if (count < ctx->opts.wide_below && !vp->wide) vp = &kVariants[kWideVariant - 1];      // small launch: the shorter dependent chain wins
-    if (vp->noSpill && scene->info.inner_height > uint32_t(vp->stackLevels())) vp = &kVariants[kSpillFallback - 1];   // tall tree
+    if (count < ctx->opts.wide_below && !vp->wide) vp = variantById(kWideVariant);      // small launch: the shorter dependent chain wins
+    if (vp->noSpill && scene->info.inner_height > uint32_t(vp->stackLevels())) vp = variantById(kSpillFallback);   // tall tree
     const Variant& v = *vp;
     const uint32_t ldsBytes = uint32_t(v.cacheNodes) * 64u + uint32_t(v.ldsLevels) * uint32_t(v.block) * 4u + (v.ldsLevels > 32 ? 272u : 0u) +
                               uint32_t(v.stagePerWave) * uint32_t(v.block / 64);
@@ -445,8 +407,11 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
         chainGuard.lock();
         chainIdx = ctx->chainHead % racc_hip_ctx::kChainRing;
         if (chainIdx == 0 && ctx->chainHead != 0) {      // a lap of the ring: every cursor word must be zero again before it is handed out
-            for (uint32_t i = 0; i < ctx->opts.lanes; ++i)      // (chained launches only ever go to the lanes' own streams)
-                if (ctx->lanes[i].everLaunched) HIP_TRY(hipEventSynchronize(ctx->lanes[i].done), "hipEventSynchronize(chain lap)");
+            // Every chained kernel was enqueued on a lane's own stream while chainMutex was held, so draining those streams here (the
+            // mutex is held again) ends every kernel that can still look at the ring.  Not the lanes' `done` events: another host
+            // thread records its lane's `done` only after it has left launchTraverse — this thread would see the previous one.
+            for (uint32_t i = 0; i < ctx->opts.lanes; ++i)
+                HIP_TRY(hipStreamSynchronize(ctx->lanes[i].stream), "hipStreamSynchronize(chain lap)");
             HIP_TRY(hipStreamSynchronize(ctx->chainStream), "hipStreamSynchronize(chain)");
             HIP_TRY(hipMemset(ctx->chainCursors, 0, size_t(racc_hip_ctx::kChainRing) * 64), "hipMemset(chain cursors)");
             // ... and no descriptor may keep a link of the lap before: a kernel can look at its own descriptor before the publish
@@ -490,8 +455,9 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.cacheCount = scene->info.node_count < uint32_t(v.cacheNodes) ? scene->info.node_count : uint32_t(v.cacheNodes);
     a.nodeBytes = scene->info.node_count * 64u;
     a.nodesSoa = scene->nodesSoa; a.nodeCount = scene->info.node_count;
+    if (v.wide && !scene->nodesWide) return fail(RACC_HIP_ERR_INVALID, "a 4-wide kernel needs a scene uploaded through a context created with kernel_variant 45-49 or wide_below");
     if (v.wide) { a.nodes = scene->nodesWide; a.nodeCount = scene->wideCount; a.nodeBytes = scene->wideCount * 128u; }
-    if (&v == &kVariants[kSoaVariant - 1] && !scene->nodesSoa) return fail(RACC_HIP_ERR_INVALID, "the SoA ablation variant needs a scene uploaded through a context created with that variant");
+    if (v.id == kSoaVariant && !scene->nodesSoa) return fail(RACC_HIP_ERR_INVALID, "the SoA ablation variant needs a scene uploaded through a context created with that variant");
     a.pairBytes = scene->info.pair_count * 48u;
     a.env = env ? env->pixels : nullptr;
     a.envW = env ? env->width : 0; a.envH = env ? env->height : 0;
@@ -672,7 +638,7 @@ int racc_hip_lane_count(const racc_hip_ctx* ctx, uint32_t* lanes, uint32_t* auto
 
 int racc_hip_variant_available(uint32_t kernel_variant) {
     if (kernel_variant == 0u) return 1;
-    return kernel_variant <= uint32_t(kNumVariants) && kVariants[kernel_variant - 1].kernel != nullptr ? 1 : 0;
+    return variantById(kernel_variant) ? 1 : 0;
 }
 
 int racc_hip_device_count(int* count) {
@@ -708,7 +674,7 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
         memcpy(&ctx->opts, opts, n_copy);
     }
     ctx->opts.struct_size = sizeof(racc_hip_options);
-    if (ctx->opts.kernel_variant > uint32_t(kNumVariants) || (ctx->opts.kernel_variant && !kVariants[ctx->opts.kernel_variant - 1].kernel)) {
+    if (ctx->opts.kernel_variant && !variantById(ctx->opts.kernel_variant)) {
         delete ctx;
         return fail(RACC_HIP_ERR_INVALID, "kernel_variant is not in this build (experimental kernels: make EXPERIMENTAL=1)");
     }
@@ -806,7 +772,8 @@ int racc_hip_scene_upload(racc_hip_ctx* ctx, const void* nodes64, uint32_t node_
         if (e == hipSuccess) e = hipMemcpy(s->nodesSoa, planes.data(), nb, hipMemcpyHostToDevice);
     }
     size_t wb = 0;
-    if (e == hipSuccess) {
+    // the 4-wide copy of the tree only for contexts that can select a wide kernel (it costs as much device memory as the nodes)
+    if (e == hipSuccess && (pickVariant(ctx, info.inner_height).wide || ctx->opts.wide_below != 0u)) {
         std::vector<WideNode> wide;
         collapseWide(static_cast<const GpuNodeHost*>(nodes64), node_count, wide, s->wideStack);
         s->wideCount = uint32_t(wide.size());
@@ -1017,7 +984,7 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
             h = new (std::nothrow) Lane();
             if (!h) return fail(RACC_HIP_ERR_NOMEM, "out of host memory");
             const hipError_t e = initLane(*h, false);
-            if (e != hipSuccess) return fail(RACC_HIP_ERR_DEVICE, "helper lane setup", e);
+            if (e != hipSuccess) { freeLane(*h); delete h; h = nullptr; return fail(RACC_HIP_ERR_DEVICE, "helper lane setup", e); }
         }
     Lane* const run[3] = {nHelpers == 3u ? l.helper[2] : &l, l.helper[0], l.helper[1]};
     if (!l.copyIn) HIP_TRY(hipStreamCreateWithFlags(&l.copyIn, hipStreamNonBlocking), "hipStreamCreate");
@@ -1046,6 +1013,7 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
     for (uint32_t k = 0; k < slices; ++k) {
         const uint64_t g0 = cut[k], g1 = cut[k + 1];
         Lane& r = *run[k % 3u];           // the three take the slices' kernels in turn: a slice's drain overlaps the next one's bulk
+        struct GridGuard { Lane& l; ~GridGuard() { l.forceWavesPerSimd = 0u; } } gridGuard{r};      // (also on the error returns below)
         r.forceWavesPerSimd = 3u;
         HIP_TRY(copyRange(0, g0, g1, l.copyIn), "H2D rays");
         HIP_TRY(hipEventRecord(l.pipeEvents[2 * k], l.copyIn), "hipEventRecord");
@@ -1055,7 +1023,6 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
         HIP_TRY(hipEventRecord(l.pipeEvents[2 * k + 1], r.stream), "hipEventRecord");
         HIP_TRY(hipStreamWaitEvent(l.copyOut, l.pipeEvents[2 * k + 1], 0), "hipStreamWaitEvent");
         HIP_TRY(copyRange(1, g0, g1, l.copyOut), "D2H results");
-        r.forceWavesPerSimd = 0u;
     }
     for (Lane* h : l.helper) if (h) HIP_TRY(hipStreamSynchronize(h->stream), "hipStreamSynchronize");
     HIP_TRY(hipStreamSynchronize(l.copyOut), "hipStreamSynchronize");

@@ -116,14 +116,12 @@ _lib = None
 
 def build_library(force=False):
     """Compile libracc_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("racc_hip.hip", "racc_device.inc", "racc_kernel_v8.inc", "racc_kernels_experimental.inc", "scene_build.cpp", "racc_api.cpp", "pathtracer.cpp", "pt_device.hip", "pt_shade.h",
-                                                 "pt_scene.h", "Makefile")]
-    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("racc_hip.h", "RayAccelerator.h")]
-    srcs.append(os.path.join(_HERE, "..", "tests", "cpp", "render_check.cpp"))
     outs = [LIB_PATH, API_LIB_PATH, PT_LIB_PATH, PTDEV_LIB_PATH, os.path.join(_HERE, "..", "tests", "cpp", "render_check")]
-    stale = any(not os.path.exists(o) for o in outs) or any(os.path.getmtime(s) > min(os.path.getmtime(o) for o in outs) for s in srcs)
-    if force or stale:
-        subprocess.check_call(["make", "-s", "-C", CSRC])
+    if force:
+        for o in outs:
+            if os.path.exists(o):
+                os.remove(o)
+    subprocess.check_call(["make", "-s", "-C", CSRC])      # make knows every dependency (the kernels' .inc files included): no second list here
     return LIB_PATH
 
 
