@@ -12,7 +12,11 @@
  * 192-194); only the ORDER in which the hit children are visited is the wide node's own: nearest entry distance first.
  *
  * Build: gcc -O2 -ffp-contract=off -mavx2 -mfma -o wide_sim wide_sim.c -lm -lpthread   (includes racc_oracle.c)
- * Run:   wide_sim nodes.bin pairs.bin rays.bin [order]      order 0 = full sort (default), 1 = only the nearest child exact
+ * Run:   wide_sim nodes.bin pairs.bin remap.bin rays.bin [order] [maxrays] [quant]
+ *        order 0 = full sort (default), 1 = only the nearest child exact
+ *        quant 1 = the 64-byte compressed node of racc_kernel_v10.inc: the four child boxes quantised conservatively to 8 bits
+ *                  per plane on the box that encloses them (origin + q * scale, decoded with one fmaf exactly as the kernel
+ *                  does); every decoded box contains the reference's box, so every box the reference enters is entered.
  */
 #include "racc_oracle.c"
 
@@ -75,7 +79,34 @@ static uint32_t collapse(const orc_gpu_node* nodes, uint32_t nodeCount, wide_nod
     return count;
 }
 
-typedef struct { unsigned long long nv, np, depthSum, depthMax, slots[5]; } wstats;
+/* Conservative 8-bit quantisation of one wide node, in place: lo/hi are replaced by what the kernel decodes.  The frame is the
+ * box around the (used) children: origin = its lower corner, scale = extent / 255 rounded up until fmaf(255, scale, origin)
+ * reaches the upper corner.  A lower plane takes the largest q whose decoded value does not exceed it, an upper plane the
+ * smallest q whose decoded value is not below it — checked with the very fmaf the kernel evaluates. */
+static void quantise_node(wide_node* w, double* growth) {
+    for (int a = 0; a < 3; ++a) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int i = 0; i < 4; ++i) if (w->ref[i]) { lo = omin(lo, w->lo[a][i]); hi = omax(hi, w->hi[a][i]); }
+        float scale = (hi - lo) / 255.0f;
+        if (!(scale > 0.0f)) scale = 1.17549435e-38f;
+        while (fmaf(255.0f, scale, lo) < hi) scale = nextafterf(scale, INFINITY);
+        for (int i = 0; i < 4; ++i) {
+            if (!w->ref[i]) continue;
+            int ql = (int)floorf((w->lo[a][i] - lo) / scale), qh = (int)ceilf((w->hi[a][i] - lo) / scale);
+            if (ql < 0) ql = 0; if (ql > 255) ql = 255; if (qh < 0) qh = 0; if (qh > 255) qh = 255;
+            while (ql > 0 && fmaf((float)ql, scale, lo) > w->lo[a][i]) --ql;
+            while (ql < 255 && fmaf((float)(ql + 1), scale, lo) <= w->lo[a][i]) ++ql;
+            while (qh < 255 && fmaf((float)qh, scale, lo) < w->hi[a][i]) ++qh;
+            while (qh > 0 && fmaf((float)(qh - 1), scale, lo) >= w->hi[a][i]) --qh;
+            const float dl = fmaf((float)ql, scale, lo), dh = fmaf((float)qh, scale, lo);
+            if (dl > w->lo[a][i] || dh < w->hi[a][i]) { fprintf(stderr, "quantise: not conservative\n"); exit(4); }
+            if (growth) *growth += (double)(w->lo[a][i] - dl) + (double)(dh - w->hi[a][i]);
+            w->lo[a][i] = dl; w->hi[a][i] = dh;
+        }
+    }
+}
+
+typedef struct { unsigned long long nv, np, depthSum, depthMax, slots[5], depthHist[64], deepVisits[64]; } wstats;
 
 static void traverse_wide(const wide_node* nodes, const orc_pair* pairs, const uint32_t* remap, const orc_ray* in, orc_result* out, int order, wstats* st) {
     ray_state ray;
@@ -90,7 +121,7 @@ static void traverse_wide(const wide_node* nodes, const orc_pair* pairs, const u
     for (;;) {
         if (node & 0x80000000u) {
             const wide_node* n = nodes + (node & 0x7FFFFFFFu);
-            ++st->nv;
+            ++st->nv; ++st->deepVisits[head < 63 ? head : 63];      /* stack height at this visit */
             const float tRay = ray.tFar;
             float key[4]; uint32_t ref[4];
             for (int i = 0; i < 4; ++i) {
@@ -135,6 +166,7 @@ static void traverse_wide(const wide_node* nodes, const orc_pair* pairs, const u
         node = stack[--head];
     }
     st->depthSum += maxDepth; if (maxDepth > st->depthMax) st->depthMax = maxDepth;
+    ++st->depthHist[maxDepth < 63 ? maxDepth : 63];
     if (hit.index == -1) { out->triangle = 0xFFFFFFFFu; out->t = out->u = out->v = 0.0f; }
     else {
         uint32_t index = remap[hit.index];
@@ -166,10 +198,12 @@ int main(int argc, char** argv) {
     if (argc > 6 && (uint32_t)atoi(argv[6]) < count) count = (uint32_t)atoi(argv[6]);
     wide_node* wide = aligned_alloc(128, sizeof(wide_node) * nodeCount);
     const uint32_t wideCount = collapse(nodes, nodeCount, wide, 0);
+    const int quant = argc > 7 ? atoi(argv[7]) : 0;
+    if (quant) { double growth = 0.0; for (uint32_t i = 0; i < wideCount; ++i) quantise_node(wide + i, &growth); fprintf(stderr, "quantised %u nodes, mean plane displacement %.3g\n", wideCount, growth / (24.0 * wideCount)); }
     unsigned long long full = 0;
     for (uint32_t i = 0; i < wideCount; ++i) { int k = 0; for (int j = 0; j < 4; ++j) k += wide[i].ref[j] != 0; full += (unsigned)k; }
     wstats st; memset(&st, 0, sizeof(st));
-    unsigned long long nv2 = 0, np2 = 0, d2 = 0, ties = 0, diffs = 0, d2max = 0;
+    unsigned long long nv2 = 0, np2 = 0, d2 = 0, ties = 0, diffs = 0, d2max = 0, closer = 0;
     for (uint32_t i = 0; i < count; ++i) {
         orc_result a, b; uint32_t nv, np, dp;
         traverse_one(nodes, pairs, remap, 0, 0, 0, rays + i, &a, &nv, &np, &dp);
@@ -180,13 +214,19 @@ int main(int argc, char** argv) {
         traverse_wide(wide, pairs, remap, rays + i, &b, order, &st);
         if (a.triangle != b.triangle || f2u(a.t) != f2u(b.t) || f2u(a.u) != f2u(b.u) || f2u(a.v) != f2u(b.v)) {
             if (a.triangle != 0xFFFFFFFFu && b.triangle != 0xFFFFFFFFu && fabsf(a.t - b.t) <= 1e-6f * fabsf(a.t)) ++ties;
+            else if (quant && b.triangle != 0xFFFFFFFFu && (a.triangle == 0xFFFFFFFFu || b.t < a.t)) ++closer;      /* the larger boxes let a hit through that the reference's own box test culled (box vs triangle rounding): a closer hit, not a wrong one */
             else { ++diffs; if (diffs < 5) fprintf(stderr, "diff ray %u: %u %g %g %g | %u %g %g %g\n", i, a.triangle, a.t, a.u, a.v, b.triangle, b.t, b.u, b.v); }
         }
     }
     printf("{\"rays\": %u, \"order\": %d, \"bvh2_nodes\": %u, \"wide_nodes\": %u, \"slots_used\": %.2f, \"nv2\": %.2f, \"np2\": %.2f, \"depth2_mean\": %.2f, \"depth2_max\": %llu, "
-           "\"nv4\": %.2f, \"np4\": %.2f, \"depth4_mean\": %.2f, \"depth4_max\": %llu, \"hits_per_visit\": [%.3f, %.3f, %.3f, %.3f, %.3f], \"ties\": %llu, \"differences\": %llu}\n",
+           "\"nv4\": %.2f, \"np4\": %.2f, \"depth4_mean\": %.2f, \"depth4_max\": %llu, \"hits_per_visit\": [%.3f, %.3f, %.3f, %.3f, %.3f], \"ties\": %llu, \"closer_than_reference\": %llu, \"differences\": %llu}\n",
            count, order, nodeCount, wideCount, (double)full / wideCount, (double)nv2 / count, (double)np2 / count, (double)d2 / count, d2max,
            (double)st.nv / count, (double)st.np / count, (double)st.depthSum / count, st.depthMax,
-           (double)st.slots[0] / st.nv, (double)st.slots[1] / st.nv, (double)st.slots[2] / st.nv, (double)st.slots[3] / st.nv, (double)st.slots[4] / st.nv, ties, diffs);
+           (double)st.slots[0] / st.nv, (double)st.slots[1] / st.nv, (double)st.slots[2] / st.nv, (double)st.slots[3] / st.nv, (double)st.slots[4] / st.nv, ties, closer, diffs);
+    if (getenv("WIDE_SIM_HIST")) {
+        fprintf(stderr, "rays by deepest stack / visits by stack height at the visit:\n");
+        unsigned long long cr = 0, cv = 0;
+        for (int d = 0; d < 64; ++d) { cr += st.depthHist[d]; cv += st.deepVisits[d]; if (st.depthHist[d] || st.deepVisits[d]) fprintf(stderr, "  %2d: rays %8llu (cum %.5f)  visits %10llu (cum %.5f)\n", d, st.depthHist[d], (double)cr / count, st.deepVisits[d], (double)cv / st.nv); }
+    }
     return diffs ? 1 : 0;
 }

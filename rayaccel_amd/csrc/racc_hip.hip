@@ -29,6 +29,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -52,6 +53,8 @@ namespace {
 #include "racc_kernel_v8.inc"
 
 #include "racc_kernel_v9.inc"
+
+#include "racc_kernel_v10.inc"
 
 #ifdef RACC_EXPERIMENTAL
 #include "racc_kernels_experimental.inc"      // V1..V7: earlier generations and ablations, tools/experimental/, `make EXPERIMENTAL=1`
@@ -149,12 +152,15 @@ struct racc_hip_ctx {
     std::mutex chainMutex;
     struct { const racc_hip_scene* scene = nullptr; const racc_hip_env* env = nullptr; const void* kernel = nullptr; uint32_t idx = 0; Lane* lane = nullptr; bool valid = false; } chainLast;
     bool chainEnabled = true;            // RACC_CHAIN=0 switches it off
+    uint32_t debugFlags = 0;             // RACC_DEBUG_FLAGS: bit 0 = V10 requests node records for every lane (A/B only)
+    bool raysBypassL1 = true;            // chained kernels load rays with system-scope loads (RACC_RAY_SCOPE=0: plain loads, A/B only)
     uint32_t maxIters = 1u << 24;        // RACC_MAX_ITERS overrides (tests)
 };
 
 struct racc_hip_scene {
     float4* nodes = nullptr;
     float4* nodesWide = nullptr;    // the same tree collapsed into 4-wide 128 B records (collapseWide)
+    float4* nodesWideQ = nullptr;   // ... and those compressed to 64 B: child boxes quantised to 8 bits per plane on the box around them (quantiseWide)
     uint32_t wideCount = 0;
     uint32_t wideStack = 0;         // upper bound of a ray's stack entries in the wide tree
     float4* nodesSoa = nullptr;     // only when the context asks for the SoA ablation variant
@@ -316,6 +322,55 @@ void collapseWide(const GpuNodeHost* in, uint32_t n, std::vector<WideNode>& out,
     stackBound = 3u * height + 1u;      // at most three entries per level of the path
 }
 
+// Compressed 4-wide device format (racc_kernel_v10.inc): the record of collapseWide in 64 bytes.  Frame = the box around the
+// used children: origin = its lower corner, scale = extent / 255, raised until fmaf(255, scale, origin) reaches the upper corner.
+// A lower plane takes the largest byte whose decoded value — fmaf(float(byte), scale, origin), the kernel's expression, one
+// rounding — does not exceed it, an upper plane the smallest byte whose decoded value is not below it: the decoded box contains
+// the reference's box, checked here with that very expression.  Unused slots: lower = 255, upper = 0 on every axis (entry beyond
+// exit on every axis with an extent: never entered) and the ref of a real leaf.
+struct WideNodeQ { uint32_t ref[4]; float org[3]; float sclX; float sclY, sclZ; uint32_t q[6]; };      // q: lo.x hi.x lo.y hi.y lo.z hi.z, byte i = child i
+static_assert(sizeof(WideNodeQ) == 64, "half an L1 line, like the binary record");
+
+int quantiseWide(const std::vector<WideNode>& in, std::vector<WideNodeQ>& out) {
+    out.resize(in.size());
+    for (size_t n = 0; n < in.size(); ++n) {
+        const WideNode& w = in[n];
+        WideNodeQ r{};
+        std::memcpy(r.ref, w.ref, sizeof(r.ref));
+        bool used[4];
+        for (int i = 0; i < 4; ++i) used[i] = !std::isinf(w.plane[0][i]);
+        float scl[3];
+        for (int ax = 0; ax < 3; ++ax) {
+            float lo = std::numeric_limits<float>::infinity(), hi = -lo;
+            for (int i = 0; i < 4; ++i) if (used[i]) { lo = std::fmin(lo, w.plane[2 * ax][i]); hi = std::fmax(hi, w.plane[2 * ax + 1][i]); }
+            float scale = (hi - lo) / 255.0f;
+            if (!(scale > 0.0f)) scale = std::numeric_limits<float>::min();
+            while (std::fmaf(255.0f, scale, lo) < hi) scale = std::nextafter(scale, std::numeric_limits<float>::infinity());
+            if (!std::isfinite(scale) || !std::isfinite(lo)) return fail(RACC_HIP_ERR_LIMIT, "scene blob: a node's extent overflows binary32");
+            r.org[ax] = lo; scl[ax] = scale;
+            uint32_t qlo = 0, qhi = 0;
+            for (int i = 0; i < 4; ++i) {
+                int a = 255, b = 0;      // unused slot: inverted
+                if (used[i]) {
+                    const float pl = w.plane[2 * ax][i], ph = w.plane[2 * ax + 1][i];
+                    a = int(std::floor((pl - lo) / scale)); b = int(std::ceil((ph - lo) / scale));
+                    a = a < 0 ? 0 : a > 255 ? 255 : a; b = b < 0 ? 0 : b > 255 ? 255 : b;
+                    while (a > 0 && std::fmaf(float(a), scale, lo) > pl) --a;
+                    while (a < 255 && std::fmaf(float(a + 1), scale, lo) <= pl) ++a;
+                    while (b < 255 && std::fmaf(float(b), scale, lo) < ph) ++b;
+                    while (b > 0 && std::fmaf(float(b - 1), scale, lo) >= ph) --b;
+                    if (std::fmaf(float(a), scale, lo) > pl || std::fmaf(float(b), scale, lo) < ph) return fail(RACC_HIP_ERR_LIMIT, "scene blob: a child box cannot be quantised conservatively");
+                }
+                qlo |= uint32_t(a) << (8 * i); qhi |= uint32_t(b) << (8 * i);
+            }
+            r.q[2 * ax] = qlo; r.q[2 * ax + 1] = qhi;
+        }
+        r.sclX = scl[0]; r.sclY = scl[1]; r.sclZ = scl[2];
+        out[n] = r;
+    }
+    return RACC_HIP_OK;
+}
+
 int ensureSpill(racc_hip_ctx* ctx, Lane& lane, uint32_t gridThreads, uint32_t levels) {
     const size_t words = size_t(gridThreads) * (levels ? levels : 1u);
     if (lane.spillWords >= words) return RACC_HIP_OK;
@@ -341,8 +396,9 @@ struct Variant {
     int slots = 1;             // ray slots per lane (V4: 2); ldsLevels counts all of them
     int reserved = 0;          // LDS levels the kernel keeps for itself (V5: the sentinel; V6: sentinel + trash level)
     int stagePerWave = 0;      // bytes of LDS-DMA stage per wave (V6 COOP)
-    bool wide = false;         // traverses the 4-wide device format (V9)
-    void (*kernelChained)(const TraverseArgs) = nullptr;      // the instantiation whose waves can move on to the next launch of a chain (V8)
+    bool wide = false;         // traverses the 4-wide device format (V9, V10)
+    void (*kernelChained)(const TraverseArgs) = nullptr;      // the instantiation whose waves can move on to the next launch of a chain (V8, V10)
+    bool quant = false;        // ... its 64-byte compressed form (V10)
     int stackLevels() const { return (ldsLevels > 32 ? ldsLevels - (kRecFields + 1) : ldsLevels / slots) - reserved; }   // V3 rows fold the record words into ldsLevels
 };
 // kernel_variant n selects the row with id n; 0 selects the default (V8).  LDS per workgroup = cacheNodes*64 + ldsLevels*block*4
@@ -361,6 +417,10 @@ const Variant kVariants[] = {
     {47, 256, 19, 0, traverseKernelV9<256, 19, true, false>, false, true, 1, 1, 8 * 1040, true},    // 47: V9 in plain C++ + statistics (debug)
     {48, 256, 19, 0, traverseKernelV9<256, 19, false, false>, false, true, 1, 1, 8 * 1040, true},   // 48: V9 in plain C++ (A/B of the assembly block)
     {49, 256, 8, 0, traverseKernelV9<256, 8, false, true>, false, true, 1, 1, 8 * 1040, true},      // 49: variant 45 with a 7-entry LDS stack (exercises the DEEP door and the spill)
+    {50, 256, 15, 0, traverseKernelV10<256, 15, false, true>, false, true, 1, 1, 4 * 1040, true, traverseKernelV10<256, 15, false, true, true>, true},     // 50: V10 (compressed 4-wide nodes, 64 B; hot loop in assembly), 14-entry LDS stack: 5 workgroups per CU
+    {51, 256, 15, 0, traverseKernelV10<256, 15, false, false>, false, true, 1, 1, 4 * 1040, true, traverseKernelV10<256, 15, false, false, true>, true},   // 51: V10 in plain C++ (A/B and cross-check of the assembly block)
+    {52, 256, 15, 0, traverseKernelV10<256, 15, true, false>, false, true, 1, 1, 4 * 1040, true, nullptr, true},                                         // 52: V10 in plain C++ + statistics (debug)
+    {53, 256, 8, 0, traverseKernelV10<256, 8, false, true>, false, true, 1, 1, 4 * 1040, true, traverseKernelV10<256, 8, false, true, true>, true},         // 53: variant 50 with a 7-entry LDS stack (exercises the DEEP door and the spill)
 };
 constexpr int kSoaVariant = 27;
 constexpr int kWideVariant = 45;
@@ -455,17 +515,19 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.cacheCount = scene->info.node_count < uint32_t(v.cacheNodes) ? scene->info.node_count : uint32_t(v.cacheNodes);
     a.nodeBytes = scene->info.node_count * 64u;
     a.nodesSoa = scene->nodesSoa; a.nodeCount = scene->info.node_count;
-    if (v.wide && !scene->nodesWide) return fail(RACC_HIP_ERR_INVALID, "a 4-wide kernel needs a scene uploaded through a context created with kernel_variant 45-49 or wide_below");
-    if (v.wide) { a.nodes = scene->nodesWide; a.nodeCount = scene->wideCount; a.nodeBytes = scene->wideCount * 128u; }
+    if (v.wide && !(v.quant ? scene->nodesWideQ : scene->nodesWide)) return fail(RACC_HIP_ERR_INVALID, "a 4-wide kernel needs a scene uploaded through a context created with that kernel_variant (45-53) or wide_below");
+    if (v.quant) { a.nodes = scene->nodesWideQ; a.nodeCount = scene->wideCount; a.nodeBytes = scene->wideCount * 64u; }
+    else if (v.wide) { a.nodes = scene->nodesWide; a.nodeCount = scene->wideCount; a.nodeBytes = scene->wideCount * 128u; }
     if (v.id == kSoaVariant && !scene->nodesSoa) return fail(RACC_HIP_ERR_INVALID, "the SoA ablation variant needs a scene uploaded through a context created with that variant");
     a.pairBytes = scene->info.pair_count * 48u;
     a.env = env ? env->pixels : nullptr;
     a.envW = env ? env->width : 0; a.envH = env ? env->height : 0;
     a.cursor = lane.cursor;
-    a.chain = nullptr; a.chainRing = nullptr; a.rearm = 1u;
+    a.chain = nullptr; a.chainRing = nullptr; a.rearm = 1u; a.raysBypassL1 = 0u;
     if (chain) {
         a.cursor = ctx->chainCursors + size_t(chainIdx) * 16;
         a.rearm = 0u;
+        a.raysBypassL1 = ctx->raysBypassL1 ? 1u : 0u;
         a.chain = ctx->chainDev + chainIdx; a.chainRing = ctx->chainDev;
     }
     a.spill = lane.spill;
@@ -484,6 +546,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.coopDen = 100u;
     a.leafInCpp = ctx->opts.leaf_step == 2u ? 1u : 0u;
     a.noFusedStep = ctx->opts.leaf_step == 3u ? 1u : 0u;
+    a.fetchAllLanes = ctx->debugFlags & 1u;
     a.noDrainPrefetch = ctx->opts.drain_prefetch == 1u ? 0u : 1u;      // off by default: measured -3 % on a 64k-ray batch, +4..10 % on 256k-1M
     a.stats = reinterpret_cast<unsigned long long*>(lane.cursor + 8);
     // the lane's cursor / ticket / spill serve one launch at a time: a launch on another stream than the lane's previous
@@ -716,6 +779,8 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
     {
         ctx->chainEnabled = ctx->opts.chain_launches != 2u;
         if (const char* c = std::getenv("RACC_CHAIN")) ctx->chainEnabled = std::atoi(c) != 0;
+        if (const char* c = std::getenv("RACC_RAY_SCOPE")) ctx->raysBypassL1 = std::atoi(c) != 0;
+        if (const char* c = std::getenv("RACC_DEBUG_FLAGS")) ctx->debugFlags = uint32_t(std::atoi(c));
         hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&ctx->chainDev), sizeof(ChainDesc) * racc_hip_ctx::kChainRing);
         if (e1 == hipSuccess) e1 = hipMemset(ctx->chainDev, 0, sizeof(ChainDesc) * racc_hip_ctx::kChainRing);
         if (e1 == hipSuccess) {      // highest priority: a publish kernel must not wait behind the persistent waves it is meant to feed
@@ -772,14 +837,25 @@ int racc_hip_scene_upload(racc_hip_ctx* ctx, const void* nodes64, uint32_t node_
         if (e == hipSuccess) e = hipMemcpy(s->nodesSoa, planes.data(), nb, hipMemcpyHostToDevice);
     }
     size_t wb = 0;
-    // the 4-wide copy of the tree only for contexts that can select a wide kernel (it costs as much device memory as the nodes)
-    if (e == hipSuccess && (pickVariant(ctx, info.inner_height).wide || ctx->opts.wide_below != 0u)) {
+    // the 4-wide copies of the tree only for contexts that can select a wide kernel (each costs device memory like the nodes)
+    const Variant& own = pickVariant(ctx, info.inner_height);
+    if (e == hipSuccess && (own.wide || ctx->opts.wide_below != 0u)) {
         std::vector<WideNode> wide;
         collapseWide(static_cast<const GpuNodeHost*>(nodes64), node_count, wide, s->wideStack);
         s->wideCount = uint32_t(wide.size());
-        wb = wide.size() * sizeof(WideNode);
-        e = hipMalloc(reinterpret_cast<void**>(&s->nodesWide), wb);
-        if (e == hipSuccess) e = hipMemcpy(s->nodesWide, wide.data(), wb, hipMemcpyHostToDevice);
+        if (!own.quant || ctx->opts.wide_below != 0u) {
+            wb = wide.size() * sizeof(WideNode);
+            e = hipMalloc(reinterpret_cast<void**>(&s->nodesWide), wb);
+            if (e == hipSuccess) e = hipMemcpy(s->nodesWide, wide.data(), wb, hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess && own.quant) {
+            std::vector<WideNodeQ> packed;
+            if (int rc = quantiseWide(wide, packed)) { racc_hip_scene_free(ctx, s); return rc; }
+            const size_t qb = packed.size() * sizeof(WideNodeQ);
+            wb += qb;
+            e = hipMalloc(reinterpret_cast<void**>(&s->nodesWideQ), qb);
+            if (e == hipSuccess) e = hipMemcpy(s->nodesWideQ, packed.data(), qb, hipMemcpyHostToDevice);
+        }
     }
     if (e == hipSuccess) e = hipMemcpy(s->pairs, pairs48, pb, hipMemcpyHostToDevice);
     if (e == hipSuccess && rb) e = hipMemcpy(s->remap, remap, rb, hipMemcpyHostToDevice);
@@ -802,6 +878,7 @@ int racc_hip_scene_free(racc_hip_ctx* ctx, racc_hip_scene* s) {
     if (ctx) hipSetDevice(ctx->device);
     if (s->nodes) hipFree(s->nodes);
     if (s->nodesWide) hipFree(s->nodesWide);
+    if (s->nodesWideQ) hipFree(s->nodesWideQ);
     if (s->nodesSoa) hipFree(s->nodesSoa);
     if (s->pairs) hipFree(s->pairs);
     if (s->remap) hipFree(s->remap);

@@ -10,7 +10,7 @@ import pytest
 import rayaccel_amd as ra
 from oracle import oracle as orc
 from rayaccel_amd import synth
-from helpers import MISS, WIDE_VARIANTS, assert_bit_exact, assert_matches_arbiter, assert_same_closest_hit, comb_scene, make_rays
+from helpers import MISS, QUANT_VARIANTS, WIDE_VARIANTS, assert_bit_exact, assert_matches_arbiter, assert_same_closest_hit, comb_scene, make_rays
 
 pytestmark = pytest.mark.gpu
 
@@ -114,7 +114,7 @@ def test_wide_kernels_on_the_comb(gpu_ctx):
     o = np.stack([np.linspace(-20, 20, 300), np.linspace(-15, 15, 300), np.full(300, -10.0)], 1)
     rays = make_rays(o, [[0, 0, 1]] * 300)
     ref = orc.traverse(blobs, rays)
-    for variant in (45, 46, 49):
+    for variant in (45, 46, 49, 50, 51, 53):
         with ra.Context(device=0, kernel_variant=variant) as ctx:
             scene = ctx.upload_scene(blobs["nodes"], blobs["pairs"], blobs["remap"])
             assert_same_closest_hit(ctx.intersect(scene, None, rays), ref, "comb, variant %d" % variant)
@@ -128,21 +128,22 @@ def test_wide_kernels_full_size(full):
     ref_prim = orc.traverse(blobs, full["primary"], env=sc["env"], threads=8)
     bounce = synth.diffuse_bounce_rays(sc, full["primary"], ref_prim, 1 << 20)
     ref_bounce = orc.traverse(blobs, bounce, env=sc["env"], threads=8)
-    for variant in (45, 49):
+    for variant in (45, 49, 50, 53):
         with ra.Context(device=0, kernel_variant=variant) as ctx:
             scene = ctx.upload_scene(full["host"].nodes, full["host"].pairs, full["host"].remap)
             env = ctx.create_environment(sc["env"])
-            ties = assert_same_closest_hit(ctx.intersect(scene, env, full["primary"]), ref_prim, "1M coherent, variant %d" % variant)
-            ties += assert_same_closest_hit(ctx.intersect(scene, env, bounce), ref_bounce, "1M diffuse, variant %d" % variant)
-            print("variant %d: %d exact-distance ties in 2M rays" % (variant, ties))
-            # overlapped launches over the lanes
+            arb = (lambda rays: dict(vertices=sc["vertices"], indices=sc["indices"], rays=rays)) if variant in QUANT_VARIANTS else (lambda rays: None)
+            ties = assert_same_closest_hit(ctx.intersect(scene, env, full["primary"]), ref_prim, "1M coherent, variant %d" % variant, arbiter=arb(full["primary"]))
+            ties += assert_same_closest_hit(ctx.intersect(scene, env, bounce), ref_bounce, "1M diffuse, variant %d" % variant, arbiter=arb(bounce))
+            print("variant %d: %d records in 2M rays differ from the oracle (exact-distance ties%s)" % (variant, ties, ", arbiter-confirmed closer hits" if variant in QUANT_VARIANTS else ""))
+            # overlapped (chained, where the kernel has a chained instantiation) launches over the lanes
             d_r = ctx.alloc(bounce.nbytes); d_r.upload(bounce)
             outs = [ctx.alloc(len(bounce) * 16) for _ in range(3)]
             for k in range(6):
                 ctx.intersect_device(scene, env, d_r.ptr, outs[k % 3].ptr, len(bounce), lane=ra.LANE_AUTO)
             ctx.wait(ra.LANE_AUTO)
             for o in outs:
-                assert_same_closest_hit(o.download(orc.RESULT_DTYPE, len(bounce)), ref_bounce, "overlapped, variant %d" % variant)
+                assert_same_closest_hit(o.download(orc.RESULT_DTYPE, len(bounce)), ref_bounce, "overlapped, variant %d" % variant, arbiter=arb(bounce))
                 o.free()
             d_r.free(); scene.destroy(); env.destroy()
 
@@ -185,6 +186,7 @@ def test_launch_options_do_not_change_results(small_scene, small_host, small):
                 dict(waves_per_simd=3, refill_min=20, leaf_min=7, chunk=100), dict(lanes=1, chunk=64),
                 *[dict(kernel_variant=v) for v in ra.engine.available_variants()], *([dict(kernel_variant=18, regroup_period=3)] if 18 in ra.engine.available_variants() else []), dict(tail_active=65), dict(coop_same_pct=100), dict(coop_same_pct=101), dict(kernel_variant=41, coop_same_pct=100, refill_min=5, leaf_min=3, inner_reps=7), dict(leaf_step=2), dict(leaf_step=3), dict(leaf_step=2, kernel_variant=41), dict(drain_prefetch=1),
                 dict(kernel_variant=45, leaf_min=1, inner_reps=1, thin_reps=1), dict(kernel_variant=45, leaf_step=3, refill_min=5, chunk=7), dict(kernel_variant=49, leaf_min=3, inner_reps=7, tail_active=65),
+                dict(kernel_variant=50, leaf_min=1, inner_reps=1, thin_reps=1), dict(kernel_variant=50, leaf_step=3, refill_min=5, chunk=7), dict(kernel_variant=53, leaf_min=3, inner_reps=7, tail_active=65),
                 dict(chunk=1 << 30), dict(thin_reps=1, inner_reps=1), dict(thin_reps=3, tail_active=40, inner_reps=2), dict(thin_reps=64, tail_active=64), dict(inner_reps=16)):
         with ra.Context(device=0, **opt) as ctx:
             scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
@@ -298,7 +300,7 @@ def test_scheduling_statistics_variant(small_scene, small_host, small):
     visit / pair test of the oracle's count must appear as a live lane in some step."""
     rays = _batches(small)["diffuse"]
     ref, nv, npairs, _ = orc.traverse(small["blobs"], rays, counters=True)
-    for variant in [v for v in (9, 12, 21, 42, 47) if v in ra.engine.available_variants()]:
+    for variant in [v for v in (9, 12, 21, 42, 47, 52) if v in ra.engine.available_variants()]:
         with ra.Context(device=0, kernel_variant=variant) as ctx:
             scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
             ctx.read_stats()
@@ -457,8 +459,9 @@ def test_chained_launches(small_scene, small_host, small):
     other = synth.battlefield_synth(grid=24, boxes=8, quads=30)
     other_host = ra.HostScene(other["vertices"], other["indices"])
     ref_other = orc.traverse(other_host.blobs(), pool[:5000], env=small_scene["env"])
-    for chain in (0, 2):
-        with ra.Context(device=0, chain_launches=chain) as ctx:
+    for chain, variant in ((0, 0), (2, 0), (0, 50)):      # (variant 50: the compressed 4-wide kernel has a chained instantiation too)
+        check = assert_same_closest_hit if variant in WIDE_VARIANTS else assert_bit_exact
+        with ra.Context(device=0, chain_launches=chain, kernel_variant=variant) as ctx:
             scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
             scene2 = ctx.upload_scene(other_host.nodes, other_host.pairs, other_host.remap)
             env = ctx.create_environment(small_scene["env"])
@@ -479,7 +482,7 @@ def test_chained_launches(small_scene, small_host, small):
                     ctx.wait(ra.LANE_AUTO)
             ctx.wait(ra.LANE_AUTO)
             for i, (d_o, off, n, want) in enumerate(issued):
-                assert_bit_exact(d_o.download(orc.RESULT_DTYPE, n), want[off:off + n], "chain_launches=%d, launch %d (%d rays)" % (chain, i, n))
+                check(d_o.download(orc.RESULT_DTYPE, n), want[off:off + n], "chain_launches=%d, kernel_variant=%d, launch %d (%d rays)" % (chain, variant, i, n))
                 d_o.free()
             d_pool.free(); scene.destroy(); scene2.destroy(); env.destroy()
 
