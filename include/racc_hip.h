@@ -209,7 +209,7 @@ int racc_hip_stream_destroy(racc_hip_ctx* ctx, void* stream);
  * ≙ nothing in the reference (its cl_context drives devices[0], RayAccelerator.cpp:467-478).  A group is one engine context per
  * entry of `devices` (entries may repeat an ordinal: rehearsal on one GPU); the scene and the environment are replicated on
  * every member (read-only data, Scene.cpp:342-346); racc_hip_group_intersect cuts a host batch into contiguous shards of whole
- * 64-ray chunks, traces them concurrently (one host thread and one PCIe link per GPU) and lands the results in place, in order.
+ * 64-ray chunks, traces them concurrently (one persistent host thread and one PCIe link per GPU) and lands the results in place, in order.
  * No exchange between GPUs.  racc_hip_group_ctx gives the members for everything else (lanes, device-resident batches). */
 typedef struct racc_hip_group racc_hip_group;
 typedef struct racc_hip_group_scene racc_hip_group_scene;
@@ -225,6 +225,17 @@ int racc_hip_group_env_upload(racc_hip_group* group, const float* rgba, uint32_t
 int racc_hip_group_env_free(racc_hip_group* group, racc_hip_group_env* env);
 int racc_hip_group_intersect(racc_hip_group* group, const racc_hip_group_scene* scene, const racc_hip_group_env* env,
                              const void* rays, void* results, uint32_t count);
+/* Device-resident counterpart (≙ racc_hip_intersect_device per member): d_rays[i] / d_results[i] are device pointers on member i's
+ * GPU holding that member's shard of counts[i] rays (racc_hip_malloc on racc_hip_group_ctx(group, i), or the host's own allocator);
+ * a member with counts[i] == 0 sits the call out.  Asynchronous: the call hands every shard to its member's worker thread, which
+ * issues it on the member's own streams — lanes rotated, launches chained, exactly as racc_hip_intersect_device(lane =
+ * RACC_HIP_LANE_AUTO, stream = NULL) — so a caller that issues batch after batch keeps all GPUs full without a host thread of its
+ * own per GPU.  The arrays belong to the engine until racc_hip_group_wait returns; it waits for everything issued on every
+ * member and reports the first failure (a watchdog trip included).  No exchange between the members; a GPU-side consumer that
+ * needs every hit everywhere gathers afterwards (racc_hip_allgather_results, one communicator rank per member). */
+int racc_hip_group_intersect_device(racc_hip_group* group, const racc_hip_group_scene* scene, const racc_hip_group_env* env,
+                                    const void* const* d_rays, void* const* d_results, const uint32_t* counts);
+int racc_hip_group_wait(racc_hip_group* group);
 
 /* ---- multi-GPU: hit-record exchange over RCCL/xGMI ------------------------------------------------
  * The path shards without any exchange: rays never interact, the scene is read-only (Scene.cpp:342-346), so every GPU

@@ -42,11 +42,19 @@ typedef struct racc_pt_stats {     // same layout as pathtracer.cpp's
 int racc_ptdev_render_file(const char* scene_bin, int device, uint32_t width, uint32_t height,
                            uint32_t spp_first, uint32_t spp_count, uint32_t max_depth /* 0 = from the file */,
                            uint32_t samples_per_batch, double* rgb_sum, racc_pt_stats* stats);
+
+// Test hook: the next racc_ptdev_render_file call copies the ray buffer the engine was handed in bounce round `round` (0 = the
+// first batch's primaries; rounds count over all pipelines in issue order) and the hit records it returned — at most `capacity`
+// of each — to the two host arrays (Ray 32 B, Result 16 B), so that a test can re-trace exactly what the device consumer traced
+// with the oracle.  *count = records copied (0 if the render had fewer rounds).  One-shot; capacity 0 disarms.
+void racc_ptdev_capture_round(uint32_t round, void* rays_out, void* hits_out, uint32_t capacity, uint32_t* count);
 }
 
 namespace {
 
 using namespace ptshade;
+
+struct Capture { uint32_t round = 0; void* rays = nullptr; void* hits = nullptr; uint32_t capacity = 0; uint32_t* count = nullptr; } g_capture;
 
 // Pixels are walked in 8x8 blocks so that the 64 rays of a wave start out as one coherent bundle.
 __global__ void __launch_bounds__(256) ptGenKernel(Camera cam, uint32_t width, uint32_t regionW, uint32_t regionH,
@@ -128,6 +136,11 @@ __global__ void __launch_bounds__(kShadeBlock) ptShadeKernel(const ShadeTri* tri
     } while (0)
 
 }  // namespace
+
+extern "C" void racc_ptdev_capture_round(uint32_t round, void* rays_out, void* hits_out, uint32_t capacity, uint32_t* count) {
+    g_capture = Capture{round, rays_out, hits_out, (rays_out && hits_out) ? capacity : 0u, count};
+    if (count) *count = 0;
+}
 
 extern "C" int racc_ptdev_render_file(const char* scene_bin, int device, uint32_t width, uint32_t height,
                                       uint32_t spp_first, uint32_t spp_count, uint32_t max_depth,
@@ -217,6 +230,14 @@ extern "C" int racc_ptdev_render_file(const char* scene_bin, int device, uint32_
         auto bounce = [&](int p) -> int {
             Pipe& P = pipe[p];
             if (racc_hip_intersect_device(ctx, scene, env, P.rays[P.cur], P.hits, P.n, uint32_t(p), P.stream) != RACC_HIP_OK) return -3;
+            if (g_capture.capacity && g_capture.round == rounds) {      // test hook: hand this round's rays and hits to the host
+                const uint32_t n = P.n < g_capture.capacity ? P.n : g_capture.capacity;
+                if (racc_hip_stream_synchronize(ctx, P.stream) != RACC_HIP_OK) return -3;
+                if (hipMemcpy(g_capture.rays, P.rays[P.cur], size_t(n) * sizeof(RayRec), hipMemcpyDeviceToHost) != hipSuccess) return -4;
+                if (hipMemcpy(g_capture.hits, P.hits, size_t(n) * sizeof(HitRec), hipMemcpyDeviceToHost) != hipSuccess) return -4;
+                if (g_capture.count) *g_capture.count = n;
+                g_capture.capacity = 0;
+            }
             raysTraced += P.n; ++rounds;
             if (hipMemsetAsync(P.dCount, 0, 4, P.stream) != hipSuccess) return -4;
             const uint32_t need = (P.n + uint32_t(kShadeBlock) - 1u) / uint32_t(kShadeBlock);

@@ -34,6 +34,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <limits>
 #include <new>
 #include <queue>
@@ -1337,7 +1341,50 @@ int racc_hip_comm_destroy(racc_hip_comm* comm) {
 // The path shards with no exchange (rays never interact, the scene is read-only, Scene.cpp:342-346): a group is n engine
 // contexts, the scene and environment replicated on each, a batch cut into n contiguous shards (multiples of 64 rays, one
 // wave's chunk) traced concurrently, results in place.  Entries of `devices` may repeat an ordinal (rehearsal on one GPU).
-struct racc_hip_group { std::vector<racc_hip_ctx*> ctx; };
+// One persistent host thread per member (a member = one GPU): every call hands its per-member work to that thread, so the n GPUs
+// are driven concurrently without creating threads per call, and each member's HIP calls stay on one thread.
+namespace {
+struct GroupWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    uint64_t posted = 0, finished = 0;
+    bool stop = false;
+    int rc = RACC_HIP_OK;              // first failure of a posted job since the last collect()
+    std::string msg;
+    void run() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || !q.empty(); });
+            if (q.empty()) return;      // stop, and nothing left
+            std::function<void()> job = std::move(q.front());
+            q.pop_front();
+            lk.unlock();
+            job();
+            lk.lock();
+            ++finished;
+            cv.notify_all();
+        }
+    }
+    void post(std::function<void()> job) {
+        { std::lock_guard<std::mutex> g(m); q.push_back(std::move(job)); ++posted; }
+        cv.notify_all();
+    }
+    void drain() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return finished == posted; }); }
+    void note(int code) {               // called from a job, on the worker thread: keeps the first failure and its thread-local text
+        if (code == RACC_HIP_OK) return;
+        std::lock_guard<std::mutex> g(m);
+        if (rc == RACC_HIP_OK) { rc = code; msg = racc_hip_last_error(); }
+    }
+    int collect(std::string& text) { std::lock_guard<std::mutex> g(m); const int r = rc; if (r != RACC_HIP_OK) text = msg; rc = RACC_HIP_OK; msg.clear(); return r; }
+};
+}  // namespace
+
+struct racc_hip_group {
+    std::vector<racc_hip_ctx*> ctx;
+    std::vector<std::unique_ptr<GroupWorker>> worker;
+};
 struct racc_hip_group_scene { std::vector<racc_hip_scene*> scene; };
 struct racc_hip_group_env { std::vector<racc_hip_env*> env; };
 
@@ -1350,6 +1397,9 @@ int racc_hip_group_create(const int* devices, uint32_t n, const racc_hip_options
         racc_hip_ctx* c = nullptr;
         if (int rc = racc_hip_create(devices[i], opts, &c)) { racc_hip_group_destroy(g); return rc; }
         g->ctx.push_back(c);
+        g->worker.emplace_back(new GroupWorker());
+        GroupWorker* w = g->worker.back().get();
+        w->th = std::thread([w] { w->run(); });
     }
     *out = g;
     return RACC_HIP_OK;
@@ -1357,6 +1407,11 @@ int racc_hip_group_create(const int* devices, uint32_t n, const racc_hip_options
 
 int racc_hip_group_destroy(racc_hip_group* g) {
     if (!g) return RACC_HIP_OK;
+    for (auto& w : g->worker) {
+        { std::lock_guard<std::mutex> lk(w->m); w->stop = true; }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+    }
     for (racc_hip_ctx* c : g->ctx) racc_hip_destroy(c);
     delete g;
     return RACC_HIP_OK;
@@ -1409,6 +1464,14 @@ int racc_hip_group_env_free(racc_hip_group* g, racc_hip_group_env* e) {
     return RACC_HIP_OK;
 }
 
+namespace {
+int groupCollect(racc_hip_group* g) {       // after the workers have drained: the first member's failure, if any
+    int rc = RACC_HIP_OK; std::string text;
+    for (auto& w : g->worker) { std::string t; const int r = w->collect(t); if (r != RACC_HIP_OK && rc == RACC_HIP_OK) { rc = r; text = t; } }
+    return rc == RACC_HIP_OK ? RACC_HIP_OK : fail(rc, text.c_str());
+}
+}  // namespace
+
 int racc_hip_group_intersect(racc_hip_group* g, const racc_hip_group_scene* scene, const racc_hip_group_env* env,
                              const void* rays, void* results, uint32_t count) {
     if (!g || !scene || scene->scene.size() != g->ctx.size() || (env && env->env.size() != g->ctx.size()))
@@ -1417,23 +1480,52 @@ int racc_hip_group_intersect(racc_hip_group* g, const racc_hip_group_scene* scen
     if (!rays || !results) return fail(RACC_HIP_ERR_INVALID, "rays/results is NULL");
     const uint32_t n = uint32_t(g->ctx.size());
     const uint32_t per = ((count + n - 1u) / n + 63u) / 64u * 64u;        // contiguous shards, whole chunks of 64 rays
-    std::vector<int> rc(n, RACC_HIP_OK);
-    std::vector<std::string> msg(n);
-    std::vector<std::thread> workers;
     for (uint32_t i = 0; i < n; ++i) {
         const uint64_t b = uint64_t(i) * per;
         if (b >= count) break;
         const uint32_t cnt = uint32_t(uint64_t(count) - b < per ? uint64_t(count) - b : per);
-        workers.emplace_back([=, &rc, &msg] {     // one host thread per GPU: the blocking entry copies in, traces, copies out
-            rc[i] = racc_hip_intersect(g->ctx[i], scene->scene[i], env ? env->env[i] : nullptr, static_cast<const char*>(rays) + b * 32,
-                                       static_cast<char*>(results) + b * 16, cnt, 0);
-            if (rc[i] != RACC_HIP_OK) msg[i] = racc_hip_last_error();
+        GroupWorker* w = g->worker[i].get();
+        racc_hip_ctx* c = g->ctx[i];
+        const racc_hip_scene* sc = scene->scene[i];
+        const racc_hip_env* ev = env ? env->env[i] : nullptr;
+        w->post([=] {      // the member's thread and PCIe link: the blocking entry copies in, traces, copies out
+            w->note(racc_hip_intersect(c, sc, ev, static_cast<const char*>(rays) + b * 32, static_cast<char*>(results) + b * 16, cnt, 0));
         });
     }
-    for (std::thread& t : workers) t.join();
+    for (auto& w : g->worker) w->drain();
+    return groupCollect(g);
+}
+
+int racc_hip_group_intersect_device(racc_hip_group* g, const racc_hip_group_scene* scene, const racc_hip_group_env* env,
+                                    const void* const* d_rays, void* const* d_results, const uint32_t* counts) {
+    if (!g || !scene || scene->scene.size() != g->ctx.size() || (env && env->env.size() != g->ctx.size()))
+        return fail(RACC_HIP_ERR_INVALID, "group_intersect_device: the scene/environment does not belong to this group");
+    if (!d_rays || !d_results || !counts) return fail(RACC_HIP_ERR_INVALID, "group_intersect_device: NULL array");
+    const uint32_t n = uint32_t(g->ctx.size());
     for (uint32_t i = 0; i < n; ++i)
-        if (rc[i] != RACC_HIP_OK) return fail(rc[i], msg[i].c_str());
+        if (counts[i] && (!d_rays[i] || !d_results[i])) return fail(RACC_HIP_ERR_INVALID, "group_intersect_device: NULL shard");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!counts[i]) continue;
+        GroupWorker* w = g->worker[i].get();
+        racc_hip_ctx* c = g->ctx[i];
+        const racc_hip_scene* sc = scene->scene[i];
+        const racc_hip_env* ev = env ? env->env[i] : nullptr;
+        const void* r = d_rays[i]; void* o = d_results[i]; const uint32_t cnt = counts[i];
+        // the member's engine context, its own streams: lanes rotated, launches chained (racc_hip_intersect_device)
+        w->post([=] { w->note(racc_hip_intersect_device(c, sc, ev, r, o, cnt, RACC_HIP_LANE_AUTO, nullptr)); });
+    }
     return RACC_HIP_OK;
+}
+
+int racc_hip_group_wait(racc_hip_group* g) {
+    if (!g) return fail(RACC_HIP_ERR_INVALID, "group is NULL");
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        GroupWorker* w = g->worker[i].get();
+        racc_hip_ctx* c = g->ctx[i];
+        w->post([=] { w->note(racc_hip_wait(c, RACC_HIP_LANE_AUTO)); });      // (behind the member's issued batches: the worker runs its jobs in order)
+    }
+    for (auto& w : g->worker) w->drain();
+    return groupCollect(g);
 }
 
 

@@ -101,6 +101,8 @@ ABI = {
     "racc_hip_group_env_upload": (_i, [_vp, _vp, _u32, _u32, _P(_vp)]),
     "racc_hip_group_env_free": (_i, [_vp, _vp]),
     "racc_hip_group_intersect": (_i, [_vp, _vp, _vp, _vp, _vp, _u32]),
+    "racc_hip_group_intersect_device": (_i, [_vp, _vp, _vp, _P(_vp), _P(_vp), _P(_u32)]),
+    "racc_hip_group_wait": (_i, [_vp]),
     "racc_hip_comm_unique_id": (_i, [_vp]),
     "racc_hip_comm_init_rank": (_i, [_vp, _vp, _i, _i, _P(_vp)]),
     "racc_hip_allgather_results": (_i, [_vp, _vp, _vp, _u32, _vp]),
@@ -415,6 +417,22 @@ class Group:
         _check(load_library().racc_hip_group_intersect(self._h, self._scene, self._env, _ptr(rays), _ptr(out), len(rays)))
         return out
 
+    def member(self, i):
+        """The i-th member's engine context as a borrowed Context (device memory helpers, lanes)."""
+        c = Context.__new__(Context)
+        c._h = C.c_void_p(load_library().racc_hip_group_ctx(self._h, i))
+        c.device, c.lanes, c.auto_lanes = None, None, None
+        return c
+
+    def intersect_device(self, d_rays, d_results, counts):
+        """Per-member device shards (lists of device pointers / ray counts); asynchronous, see wait()."""
+        n = self.size
+        pr = (C.c_void_p * n)(*d_rays); po = (C.c_void_p * n)(*d_results); cn = (C.c_uint32 * n)(*counts)
+        _check(load_library().racc_hip_group_intersect_device(self._h, self._scene, self._env, pr, po, cn))
+
+    def wait(self):
+        _check(load_library().racc_hip_group_wait(self._h))
+
     def destroy(self):
         lib = load_library()
         if self._scene:
@@ -454,6 +472,18 @@ class PathTraceStats(C.Structure):
     _fields_ = [("rays_traced", C.c_uint64), ("primary_rays", C.c_uint64), ("seconds", C.c_double),
                 ("tiles_x", C.c_uint32), ("tiles_y", C.c_uint32), ("max_depth", C.c_uint32), ("threads", C.c_uint32),
                 ("triangles", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+def path_trace_capture_round(round_index, capacity):
+    """Arms the device consumer's test hook (racc_ptdev_capture_round): the next path_trace(shading="gpu") copies the rays the
+    engine was handed in bounce round `round_index` and the hits it returned.  Returns (rays, hits, count) — numpy arrays the
+    render fills, `count` a ctypes uint32 holding how many records arrived."""
+    lib = C.CDLL(PTDEV_LIB_PATH)
+    rays, hits, count = np.zeros(capacity, RAY_DTYPE), np.zeros(capacity, RESULT_DTYPE), C.c_uint32(0)
+    lib.racc_ptdev_capture_round.restype = None
+    lib.racc_ptdev_capture_round.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.racc_ptdev_capture_round(round_index, _ptr(rays), _ptr(hits), capacity, C.byref(count))
+    return rays, hits, count
 
 
 def path_trace(scene_bin, width, height, spp_first, spp_count, device=0, max_depth=0, cpu_threads=0, shading="cpu", samples_per_batch=0):

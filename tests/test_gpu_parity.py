@@ -10,6 +10,7 @@ import pytest
 import rayaccel_amd as ra
 from oracle import oracle as orc
 from rayaccel_amd import synth
+from rayaccel_amd.shard import shard_range
 from helpers import MISS, QUANT_VARIANTS, WIDE_VARIANTS, assert_bit_exact, assert_matches_arbiter, assert_same_closest_hit, comb_scene, make_rays
 
 pytestmark = pytest.mark.gpu
@@ -138,9 +139,9 @@ def test_wide_kernels_full_size(full):
             print("variant %d: %d records in 2M rays differ from the oracle (exact-distance ties%s)" % (variant, ties, ", arbiter-confirmed closer hits" if variant in QUANT_VARIANTS else ""))
             # overlapped (chained, where the kernel has a chained instantiation) launches over the lanes
             d_r = ctx.alloc(bounce.nbytes); d_r.upload(bounce)
-            outs = [ctx.alloc(len(bounce) * 16) for _ in range(3)]
+            outs = [ctx.alloc(len(bounce) * 16) for _ in range(6)]      # (a result array belongs to its batch until the wait returns)
             for k in range(6):
-                ctx.intersect_device(scene, env, d_r.ptr, outs[k % 3].ptr, len(bounce), lane=ra.LANE_AUTO)
+                ctx.intersect_device(scene, env, d_r.ptr, outs[k].ptr, len(bounce), lane=ra.LANE_AUTO)
             ctx.wait(ra.LANE_AUTO)
             for o in outs:
                 assert_same_closest_hit(o.download(orc.RESULT_DTYPE, len(bounce)), ref_bounce, "overlapped, variant %d" % variant, arbiter=arb(bounce))
@@ -633,3 +634,43 @@ def test_device_group_shards_a_host_batch(full):
     finally:
         grp.destroy()
     assert_bit_exact(got, orc.traverse(full["blobs"], rays, env=full["sc"]["env"], threads=8), "device group")
+
+
+def test_device_group_device_resident_shards(full):
+    """racc_hip_group_intersect_device: per-member device shards, issued asynchronously from the members' persistent worker
+    threads on the members' own streams (lanes rotated, launches chained), several batches back to back, one wait at the end.
+    Entry list [0, 0, 0]: three engine contexts on the one GPU of the box.  Every batch of every member bit-exact."""
+    blobs, sc = full["blobs"], full["sc"]
+    ref_prim = orc.traverse(blobs, full["primary"], env=sc["env"], threads=8)
+    bounce = synth.diffuse_bounce_rays(sc, full["primary"], ref_prim, 1 << 20)
+    pool = np.concatenate([full["primary"], bounce])
+    ref = np.concatenate([ref_prim, orc.traverse(blobs, bounce, env=sc["env"], threads=8)])
+    grp = ra.Group([0, 0, 0])
+    try:
+        grp.upload(full["host"].nodes, full["host"].pairs, full["host"].remap, sc["env"])
+        members = [grp.member(i) for i in range(grp.size)]
+        rng = np.random.default_rng(21)
+        issued, bufs = [], []
+        for batch in range(6):
+            total = int(rng.integers(200000, len(pool)))
+            off = int(rng.integers(0, len(pool) - total + 1))
+            cuts = [shard_range(total, i, grp.size) for i in range(grp.size)]
+            if batch == 3:
+                cuts[1] = (cuts[1][0], cuts[1][0])               # a member that sits a batch out
+            d_r, d_o, cnt = [], [], []
+            for m, (b, e) in zip(members, cuts):
+                n = e - b
+                r = m.alloc(max(n, 1) * 32); o = m.alloc(max(n, 1) * 16)
+                if n:
+                    r.upload(pool[off + b: off + e])
+                d_r.append(r.ptr); d_o.append(o.ptr); cnt.append(n); bufs += [r, o]
+                issued.append((o, off + b, n))
+            grp.intersect_device(d_r, d_o, cnt)
+        grp.wait()
+        for o, off, n in issued:
+            if n:
+                assert_bit_exact(o.download(orc.RESULT_DTYPE, n), ref[off:off + n], "group member shard of %d rays" % n)
+        for b in bufs:
+            b.free()
+    finally:
+        grp.destroy()

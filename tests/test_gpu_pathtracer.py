@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from rayaccel_amd import synth
-from rayaccel_amd.engine import path_trace
+from rayaccel_amd.engine import path_trace, path_trace_capture_round
 
 pytestmark = pytest.mark.gpu
 
@@ -79,6 +79,32 @@ def test_config4_1080p_device_and_host_consumer_render_the_same_frame(tmp_path, 
     assert sg["primary_rays"] == sc_["primary_rays"] == 4 * 15 * 8 * 128 * 128
     assert sg["rays_traced"] == sc_["rays_traced"] > 2 * sg["primary_rays"]
     assert np.array_equal(g, c) and g[:1024].any() and not g[1024:].any()
+
+
+def test_config4_1080p_64spp_equals_sixteen_shards_and_a_bounce_is_retraced(tmp_path, full):
+    """BASELINE configs[4] as written: 1920x1080 x 64 spp, device-resident consumer.  The fixed-point frame and the ray count
+    equal the sum of 16 shards of 4 spp (what N ranks render, tools/pathtrace.py), and one bounce of the 64-spp render — the
+    rays the consumer's shading kernel generated and handed to the engine in round 5, the hit records it got back — is
+    re-traced by the oracle: bit-exact (so the consumer shades what the reference's traversal would have returned)."""
+    import hashlib
+    from oracle import oracle as orc
+    from helpers import assert_bit_exact
+    p = os.path.join(str(tmp_path), "full64.bin")
+    synth.write_scene_bin(p, full["sc"], viewport=(1920, 1080))
+    cap = 1 << 21
+    rays, hits, count = path_trace_capture_round(5, cap)
+    whole, sw = path_trace(p, 1920, 1080, 0, 64, shading="gpu")
+    n = int(count.value)
+    assert n > 100000 and sw["primary_rays"] == 64 * 15 * 8 * 128 * 128 and sw["rays_traced"] > 2 * sw["primary_rays"]
+    assert float(rays["minT"][:n].max()) > 0.0          # a secondary bounce (primaries start at minT = 0, PathTracingRenderer.cpp:410-422)
+    ref = orc.traverse(full["blobs"], rays[:n], env=full["sc"]["env"], threads=8)
+    assert_bit_exact(hits[:n], ref, "device consumer, 64 spp, round 5 (%d rays)" % n)
+    total, traced = np.zeros_like(whole), 0
+    for k in range(16):
+        img, st = path_trace(p, 1920, 1080, 4 * k, 4, shading="gpu")
+        total += img; traced += st["rays_traced"]
+    assert traced == sw["rays_traced"]
+    assert hashlib.md5(total.tobytes()).hexdigest() == hashlib.md5(whole.tobytes()).hexdigest() and np.array_equal(total, whole)
 
 
 def test_device_consumer_whole_tiles(scene_file):

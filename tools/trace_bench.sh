@@ -12,10 +12,10 @@ ev = []
 for f in glob.glob(root + "/*/*_kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "traverseKernel" in n or "chainPublish" in n:
-            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Queue_Id", 0) or 0), int(r.get("Grid_Size", 0) or 0), "T" if "traverse" in n else "p"))
+        if "traverseKernel" in n or "chainPublish" in n or "envShade" in n:
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Queue_Id", 0) or 0), int(r.get("Grid_Size", 0) or 0), "T" if "traverse" in n else ("e" if "envShade" in n else "p")))
 ev.sort()
-ev = ev[-52:]          # warm-up (5 + the bench's own first calls) + 20 timed (+ their publish kernels)
+ev = ev[-76:]          # warm-up (5 + the bench's own first calls) + 20 timed (+ their publish kernels)
 t0 = ev[0][0]
 for s, e, q, g, k in ev:
     print("  %s start %8.1f end %8.1f dur %7.1f us  queue %d grid %d" % (k, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, q, g))
