@@ -156,7 +156,7 @@ struct racc_hip_ctx {
     std::mutex chainMutex;
     struct { const racc_hip_scene* scene = nullptr; const racc_hip_env* env = nullptr; const void* kernel = nullptr; uint32_t idx = 0; Lane* lane = nullptr; bool valid = false; } chainLast;
     bool chainEnabled = true;            // RACC_CHAIN=0 switches it off
-    uint32_t debugFlags = 0;             // RACC_DEBUG_FLAGS: bit 0 = V10 requests node records for every lane (A/B only)
+    uint32_t debugFlags = 0;             // RACC_DEBUG_FLAGS (A/B only): bit 0 = node records are requested for every lane, bit 1 = write-through result stores
     bool raysBypassL1 = true;            // chained kernels load rays with system-scope loads (RACC_RAY_SCOPE=0: plain loads, A/B only)
     uint32_t maxIters = 1u << 24;        // RACC_MAX_ITERS overrides (tests)
 };
@@ -551,6 +551,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.leafInCpp = ctx->opts.leaf_step == 2u ? 1u : 0u;
     a.noFusedStep = ctx->opts.leaf_step == 3u ? 1u : 0u;
     a.fetchAllLanes = ctx->debugFlags & 1u;
+    a.resultsWriteThrough = (ctx->debugFlags >> 1) & 1u;
     a.noDrainPrefetch = ctx->opts.drain_prefetch == 1u ? 0u : 1u;      // off by default: measured -3 % on a 64k-ray batch, +4..10 % on 256k-1M
     a.stats = reinterpret_cast<unsigned long long*>(lane.cursor + 8);
     // the lane's cursor / ticket / spill serve one launch at a time: a launch on another stream than the lane's previous
