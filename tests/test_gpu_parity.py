@@ -187,7 +187,7 @@ def test_launch_options_do_not_change_results(small_scene, small_host, small):
                 dict(waves_per_simd=3, refill_min=20, leaf_min=7, chunk=100), dict(lanes=1, chunk=64),
                 *[dict(kernel_variant=v) for v in ra.engine.available_variants()], *([dict(kernel_variant=18, regroup_period=3)] if 18 in ra.engine.available_variants() else []), dict(tail_active=65), dict(coop_same_pct=100), dict(coop_same_pct=101), dict(kernel_variant=41, coop_same_pct=100, refill_min=5, leaf_min=3, inner_reps=7), dict(leaf_step=2), dict(leaf_step=3), dict(leaf_step=2, kernel_variant=41), dict(drain_prefetch=1),
                 dict(kernel_variant=45, leaf_min=1, inner_reps=1, thin_reps=1), dict(kernel_variant=45, leaf_step=3, refill_min=5, chunk=7), dict(kernel_variant=49, leaf_min=3, inner_reps=7, tail_active=65),
-                dict(kernel_variant=50, leaf_min=1, inner_reps=1, thin_reps=1), dict(kernel_variant=50, leaf_step=3, refill_min=5, chunk=7), dict(kernel_variant=53, leaf_min=3, inner_reps=7, tail_active=65),
+                dict(kernel_variant=50, leaf_min=1, inner_reps=1, thin_reps=1), dict(kernel_variant=50, leaf_step=3, refill_min=5, chunk=7), dict(kernel_variant=53, leaf_min=3, inner_reps=7, tail_active=65), dict(kernel_variant=50, coop_same_pct=101), dict(kernel_variant=53, coop_same_pct=100),
                 dict(chunk=1 << 30), dict(thin_reps=1, inner_reps=1), dict(thin_reps=3, tail_active=40, inner_reps=2), dict(thin_reps=64, tail_active=64), dict(inner_reps=16)):
         with ra.Context(device=0, **opt) as ctx:
             scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
@@ -312,7 +312,7 @@ def test_scheduling_statistics_variant(small_scene, small_host, small):
             # and a thin wave's second body also serves lanes that changed kind in the first one, so they under-count.
             if variant == 9:
                 assert st["inner_lanes"] == int(nv.sum()) and st["leaf_lanes"] == int(npairs.sum())
-            elif variant == 47:     # V9 in C++: a visit is a 4-wide node, about half the oracle's binary visits
+            elif variant in (47, 52):     # V9 / V10 in C++: a visit is a 4-wide node, about half the oracle's binary visits
                 assert 0.3 * int(nv.sum()) <= st["inner_lanes"] <= 0.8 * int(nv.sum()) and st["leaf_lanes"] > 0
             elif variant == 42:     # V8: the inner and leaf steps run inside the assembly block and are not counted
                 assert st["waves"] > 0 and st["refill_iters"] >= st["waves"]
