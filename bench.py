@@ -32,8 +32,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI35
 HBM_MEASURED_GBS = 6290.0      # same guide: float4-copy ceiling
 RAYS_PER_BATCH = 1 << 20
 KERNEL_NAME = "traverseKernelV8"
-PROFILE_DIR = os.path.join("profiles", "r02")      # rocprofv3 summaries of THIS command (tools/profile_bench.sh r02)
+PROFILE_DIR = os.path.join("profiles", "r03")      # rocprofv3 summaries of THIS command (tools/profile_bench.sh r03) + microbenchmark outputs
 KERNEL_SOURCES = ("rayaccel_amd/csrc/racc_kernel_v8.inc", "rayaccel_amd/csrc/racc_device.inc")
+CU_CLOCK_HZ, CUS = 2.4e9, 256
 
 
 def kernel_source_sha256():
@@ -55,6 +56,17 @@ def committed_profile():
         return None
     d["stale"] = d.get("kernel_source_sha256") != kernel_source_sha256()
     return d
+
+
+def gather_ceiling():
+    """Best rate at which a pure gather of random 64 B records runs on this part, bytes per clock per CU: measured by
+    tools/microbench/gather64.hip (mode 2: quad-cooperative LDS-DMA), output committed under profiles/<round>/ by
+    tools/microbench/run_microbench.sh.  None when that file is missing: no constant stands in for the measurement."""
+    try:
+        with open(os.path.join(ROOT, PROFILE_DIR, "microbench.json")) as f:
+            return float(json.load(f)["gather64_ceiling_B_per_clk_per_CU"])
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def usable_cores():
@@ -87,6 +99,8 @@ def main():
                     help="N > 1: also time the K steps with the RCCL all-gather of every step's hit records (racc_hip_allgather_results); implied by --mode strong")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (profiling runs)")
+    ap.add_argument("--workload", choices=("diffuse", "coherent"), default="diffuse",
+                    help="diffuse (default, the headline): 1M first-bounce diffuse rays per step (configs[2]); coherent: the 1M primary rays (configs[1]) — profiling runs of that config")
     ap.add_argument("--grid", type=int, default=700, help="height-field resolution of battlefield-synth (700 = full)")
     ap.add_argument("--engine-opts", default="", help="JSON dict of racc_hip_options overrides (kernel A/B and profiling runs only)")
     args = ap.parse_args()
@@ -138,7 +152,10 @@ def main():
 
     primary, _ = synth.primary_rays(sc["camera"], 1024, 1024)
     primary_hits = ctx.intersect(scene, env, primary)                       # GPU path, host buffers
-    if args.mode == "weak":
+    if args.workload == "coherent":
+        bounce = primary                       # configs[1]: the timed batch is the coherent primary batch itself
+        total_rays = world * len(bounce)
+    elif args.mode == "weak":
         bounce = synth.diffuse_bounce_rays(sc, primary, primary_hits, RAYS_PER_BATCH, first_sample=rank)
         total_rays = world * len(bounce)
     else:       # strong: configs[3], 8 sample sets = one 8M-ray batch; this rank's contiguous shard of it
@@ -190,6 +207,15 @@ def main():
 
     value = total_rays * args.steps / elapsed / 1e6
     launch = ctx.launch_info()
+    # The traversal kernel alone on the GPU, one launch at a time (HIP events around the kernel on the stream it is launched on):
+    # the launch duration `roofline.achieved` is computed from — in the timed region launches are chained, a kernel there either
+    # works through many batches or finds nothing left, so no per-launch duration exists.  Untimed, a few ms.
+    iso_ms = None
+    if rank == 0:
+        ctx.intersect_device_timed(scene, env, d_rays.data_ptr(), outs[-1].data_ptr(), n, 2)
+        iso_ms = float(np.mean(ctx.intersect_device_timed(scene, env, d_rays.data_ptr(), outs[-1].data_ptr(), n, 10)))
+
+    d_ref_bits = d_out.view(torch.int32).clone()      # the default kernel's records of the timed batch (the extras reuse the result arrays)
 
     # ---- optional extras, all outside the timed region ------------------------------------------
     extras = {}
@@ -236,6 +262,12 @@ def main():
         timed_serial(d_prim, d_prim_out, 2)
         pm = float(np.median(timed_serial(d_prim, d_prim_out, 10)))
         extras["coherent_1M"] = {"ms_per_step": round(pm, 4), "mrays_per_s": round(len(primary) / pm / 1e3, 1)}
+        for k in range(args.warmup + args.steps):           # configs[1] issued like the timed region: chained, lanes rotated
+            if k == args.warmup:
+                ctx.wait(ra.LANE_AUTO); torch.cuda.synchronize(); t1 = time.perf_counter()
+            ctx.intersect_device(scene, env, d_prim.data_ptr(), outs[k % len(outs)].data_ptr(), len(primary), lane=ra.LANE_AUTO)
+        ctx.wait(ra.LANE_AUTO); torch.cuda.synchronize()
+        extras["coherent_1M"]["back_to_back_mrays_per_s"] = round(len(primary) * args.steps / (time.perf_counter() - t1) / 1e6, 1)
         # PCIe-inclusive rate of the host-buffer entry point (never `value`)
         res_host = np.zeros(n, ra.RESULT_DTYPE)
         ctx.intersect(scene, env, bounce, res_host)
@@ -273,24 +305,41 @@ def main():
             slope = (scaling[str(1 << 23)] - scaling[str(1 << 20)]) / 7.0          # ms per 2^20 rays
             extras["batch_scaling"] = {"kernel_ms_by_rays": scaling, "steady_state_mrays_per_s": round((1 << 20) / slope / 1e3, 1),
                                        "fixed_ms": round(scaling[str(1 << 20)] - slope, 4)}
-            # the optional 4-wide kernel (kernel_variant 45) on the same batches: its own context, same scene blobs
+            # the compressed 4-wide kernel (kernel_variant 50, racc_kernel_v10.inc) on the same batches, its own
+            # context, same scene blobs: single launches, and the SAME loop as the timed region (K chained steps after W warm-up)
             try:
-                with ra.Context(device=device, kernel_variant=45, time_kernels=0) as wctx:
+                with ra.Context(device=device, kernel_variant=50, time_kernels=0) as wctx:
                     wscene = wctx.upload_scene(host.nodes, host.pairs, host.remap)
                     wenv = wctx.create_environment(sc["env"])
                     wide = {}
-                    for nn in (1 << 16, 1 << 18, 1 << 20, 1 << 22):
+                    for nn in (1 << 16, 1 << 18, 1 << 20, 1 << 22, 1 << 23):
                         wctx.intersect_device_timed(wscene, wenv, d_many.data_ptr(), d_many_out.data_ptr(), nn, 2)
                         wide[str(nn)] = round(float(np.median(wctx.intersect_device_timed(wscene, wenv, d_many.data_ptr(), d_many_out.data_ptr(), nn, 7))), 4)
-                    wctx.intersect_device(wscene, wenv, d_rays.data_ptr(), outs[-1].data_ptr(), n, lane=0)
-                    wctx.wait(0)
-                    differing = int((outs[-1].view(torch.int32) != d_out.view(torch.int32)).any(dim=1).sum().item())
-                    extras["wide_kernel_variant_45"] = {"kernel_ms_by_rays": wide, "default_kernel_ms_by_rays": {k: scaling[k] for k in wide},
-                                                        "records_differing_from_default_in_1M": differing,
-                                                        "note": "4-wide nodes: same closest hit (exact-distance ties may resolve to the other primitive), shorter dependent chain"}
+                    wslope = (wide[str(1 << 23)] - wide[str(1 << 20)]) / 7.0
+
+                    def wrun(steps):
+                        for k in range(steps):
+                            wctx.intersect_device(wscene, wenv, d_rays.data_ptr(), outs[k % len(outs)].data_ptr(), n, lane=ra.LANE_AUTO)
+                        wctx.wait(ra.LANE_AUTO)
+                    if args.warmup:
+                        wrun(args.warmup)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    wrun(args.steps)
+                    torch.cuda.synchronize()
+                    wdt = time.perf_counter() - t1
+                    cmp = outs[min(args.steps, len(outs)) - 1]
+                    differing = int((cmp.view(torch.int32) != d_ref_bits).any(dim=1).sum().item())
+                    extras["compressed_wide_kernel_variant_50"] = {
+                        "mrays_per_s_same_loop_as_value": round(n * args.steps / wdt / 1e6, 1), "ms_per_step": round(wdt / args.steps * 1e3, 4),
+                        "kernel_ms_by_rays": wide, "default_kernel_ms_by_rays": {k: scaling[k] for k in wide},
+                        "steady_state_mrays_per_s": round((1 << 20) / wslope / 1e3, 1), "fixed_ms": round(wide[str(1 << 20)] - wslope, 4),
+                        "records_differing_from_default_in_1M": differing,
+                        "note": "64 B 4-wide nodes, child boxes quantised conservatively to 8 bits: half the node bytes and vector-memory instructions per ray; "
+                                "same closest hit as the default kernel except exact-distance ties and arbiter-confirmed closer hits (DESIGN.md §3, §5)"}
                     wscene.destroy(); wenv.destroy()
             except ra.RaccError as e:
-                extras["wide_kernel_variant_45"] = {"error": str(e)}
+                extras["compressed_wide_kernel_variant_50"] = {"error": str(e)}
             del d_many, d_many_out
 
         # BASELINE configs[4]: the path tracer, 1920x1080, end to end on this GPU.  Device-resident consumer (generation and
@@ -323,8 +372,11 @@ def main():
             ref, nv, npairs, _ = oracle.traverse(blobs, bounce, env=sc["env"], counters=True)
             alg_bytes, src = oracle.algorithmic_bytes(ref, nv, npairs), "oracle counters, live"
             got = d_out.cpu().numpy().view(ra.RESULT_DTYPE).reshape(-1)
-            if not np.array_equal(got["triangle"], ref["triangle"]):
-                sys.exit("bench: GPU results differ from the oracle — refusing to report a number")
+            hit = ref["triangle"] != 0xFFFFFFFF
+            if not np.array_equal(got["triangle"], ref["triangle"]) or any(
+                    not np.array_equal(got[f][hit].view(np.uint32), ref[f][hit].view(np.uint32)) for f in ("t", "u", "v")) or any(
+                    not np.allclose(got[f][~hit], ref[f][~hit], rtol=1e-5, atol=1e-5) for f in ("t", "u", "v")):
+                sys.exit("bench: GPU results (primId, t, u, v bits; miss colours to 1e-5) differ from the oracle — refusing to report a number")
             threads = usable_cores()
             cpu_out = np.zeros(n, oracle.RESULT_DTYPE)
             oracle.traverse(blobs, bounce, env=sc["env"], threads=threads, out=cpu_out)          # warm-up: faults pages, starts clocks
@@ -370,48 +422,87 @@ def main():
                     src = "tests/golden/algorithmic_bytes.json"
             except (OSError, KeyError, ValueError):
                 pass
-        if avg_kernel_ms:
-            # `bound: hbm` is BASELINE's yard-stick.  The PHYSICAL HBM traffic of a launch (rocprofv3 FETCH_SIZE/WRITE_SIZE,
-            # corrected as the guide prescribes) over the kernel's duration is `achieved`: the 55 MB scene lives in L2 and the
-            # Infinity Cache, so this is a few per cent of the 8 TB/s — the kernel is nowhere near an HBM bound and the
-            # fraction says so.  The algorithmic bytes of SURVEY §8(d) (every node / pair the reference's traversal order
-            # touches) are reported beside it: they exceed what HBM could deliver, because caches serve them.  What does bind
-            # the kernel is in `limiter` (from the same committed profile).
+        golden = {}
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "algorithmic_bytes.json")) as f:
+                golden = json.load(f)
+        except (OSError, ValueError):
+            pass
+        if args.workload == "coherent" and not alg_bytes:
+            alg_bytes, src = (golden.get("coherent_1M") or {}).get("bytes") if full else None, "tests/golden/algorithmic_bytes.json"
+        prof = None
+        if iso_ms:
+            # The contract's roofline: `achieved` = the ALGORITHMIC bytes of SURVEY §8(d) per launch (every node / pair the reference's
+            # traversal order touches, counted by the oracle) over the traversal kernel's launch duration (HIP events, the kernel alone
+            # on the GPU), against the 8 TB/s of HBM.  The fraction comes out ABOVE 1: the 55 MB scene lives in the L2s and the
+            # Infinity Cache, which serve nearly all of those bytes — the work is done (every record of the timed batch is compared
+            # with the oracle above), HBM is simply not what bounds this kernel.  `traffic` = what did cross the L2-fabric boundary
+            # per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, same isolated mode, committed profile); `l1_gather` = the same
+            # algorithmic bytes against the ceiling they can be held to, the CU's vector-memory return path, measured by a
+            # microbenchmark whose output is committed beside the profile; `limiter` = the counters that say what binds it.
             prof = committed_profile()
-            traffic = prof.get("hbm_bytes_per_launch") if (prof and full and args.mode == "weak") else None      # measured on THIS workload only
-            kernels_in_flight = max(1.0, avg_kernel_ms * args.steps / (elapsed * 1e3)) if world == 1 else None
-            # launches overlap, so the GPU's HBM rate is bytes per launch over the time the region spends per launch
-            # (ms_per_step), not over one kernel's own (stretched) duration
+            on_profiled_workload = bool(prof and full and args.mode == "weak")
+            pw = (prof or {}).get("coherent" if args.workload == "coherent" else "diffuse", {}) if on_profiled_workload else {}
+            traffic = pw.get("fabric_bytes_per_launch")
             step_s = elapsed / args.steps
-            roofline = {"bound": "hbm", "achieved": round(traffic / step_s / 1e9, 1) if traffic else None,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(traffic / step_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                        "traffic": traffic,
-                        "achieved_note": "physical HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, %s) / ms_per_step of the timed region" % PROFILE_DIR,
-                        "kernel": KERNEL_NAME, "kernel_ms_avg": round(avg_kernel_ms, 4),
-                        "kernel_ms_avg_note": "HIP events around every traversal kernel of the timed region on its own stream; launches are chained (the first kernels of a sequence work on through the later batches, whose own kernels then find nothing left and last microseconds) and launches of different lanes overlap, "
-                                              "so a kernel shares the GPU with its neighbours (avg %.2f in flight) and lasts longer than alone "
-                                              "(see one_launch_at_a_time.kernel_ms_avg)" % (kernels_in_flight or 0.0),
-                        "algorithmic": None if not alg_bytes else {
-                            "bytes_per_launch": int(alg_bytes), "source": src,
-                            "gbs": round(alg_bytes / step_s / 1e9, 1),
-                            "x_hbm_peak": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
-                            "note": "served by L2 / Infinity Cache, not HBM: not a fraction of any physical ceiling"},
-                        # The algorithmic bytes DO pass through each CU's vector-L1 data-return path (every node visit's 64 B,
-                        # every pair's 48 B), so that path is the ceiling they can be held to: bytes per clock per CU against
-                        # the best rate a pure gather of random 64 B records reaches on this part (tools/microbench/gather64.hip,
-                        # quad-cooperative LDS-DMA: 4 KiB per 128 cycles per CU = 32 B/clk/CU; four dwordx4 per lane: 21.9).
-                        "l1_gather": None if not alg_bytes else {
-                            "achieved_B_per_clk_per_CU": round(alg_bytes / step_s / (256 * 2.4e9), 2),
-                            "steady_state_B_per_clk_per_CU": (round(alg_bytes / ((1 << 20) / (extras["batch_scaling"]["steady_state_mrays_per_s"] * 1e6)) / (256 * 2.4e9), 2)
-                                                              if "batch_scaling" in extras else None),
-                            "measured_gather_ceiling_B_per_clk_per_CU": 32.0,
-                            "frac": round(alg_bytes / step_s / (256 * 2.4e9) / 32.0, 4),
-                            "note": "256 CUs x 2.4 GHz; ceiling = tools/microbench/gather64 mode 2 (64 random 64 B records per wave, 6 waves/SIMD)"},
-                        "limiter": None if not prof else {k: prof.get(k) for k in (
-                            "bound", "td_busy_frac", "ta_busy_frac", "valu_busy_frac", "issue_slot_frac", "valu_lane_util", "salu_share",
-                            "l2_hit_rate", "hbm_physical_frac_isolated", "kernel_ms_isolated", "source")},
-                        "profile_stale": bool(prof["stale"]) if prof else None}
+            ceiling = gather_ceiling()
+
+            def core(alg, ms, tr):
+                if not alg or not ms:
+                    return None
+                return {"achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr,
+                        "algorithmic_bytes_per_launch": int(alg), "kernel_ms_avg": round(ms, 4),
+                        "fabric_frac_of_hbm_peak": round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr else None,
+                        "l1_gather_frac": round(alg / (ms * 1e-3) / (CUS * CU_CLOCK_HZ) / ceiling, 4) if ceiling else None}
+            c = core(alg_bytes, iso_ms, traffic) or {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": traffic, "kernel_ms_avg": round(iso_ms, 4)}
+            roofline = {"bound": "hbm"}
+            roofline.update(c)
+            roofline.update({
+                "kernel": KERNEL_NAME, "algorithmic_source": src,
+                "kernel_ms_avg_note": "HIP events around the traversal kernel on the stream it is launched on, the kernel alone on the GPU (10 launches after the timed region); "
+                                      "rocprofv3 --kernel-trace of the same command with one lane and no chaining: %s ms (%s/kernel_stats_one_lane.csv)" % (
+                                          round(pw["kernel_ms_isolated"], 4) if pw.get("kernel_ms_isolated") else "n/a", PROFILE_DIR),
+                "reading": "frac > 1 because L2 and the Infinity Cache serve the algorithmic bytes; what crossed the L2-fabric boundary is `traffic` "
+                           "(%s of the algorithmic bytes), %s of the HBM peak" % (
+                               ("%.1f %%" % (100.0 * traffic / alg_bytes)) if (traffic and alg_bytes) else "n/a",
+                               ("%.1f %%" % (100.0 * c["fabric_frac_of_hbm_peak"])) if c.get("fabric_frac_of_hbm_peak") else "n/a"),
+                "traffic_what": "L2-miss / fabric bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes, gfx950 correction of the guide), "
+                                "the kernel alone on the GPU as for `achieved`; includes Infinity-Cache hits, so an upper bound of HBM traffic; %s/pmc_summary.json" % PROFILE_DIR,
+                # the timed region: launches are chained and overlap, so the rate is bytes per launch over the time the region spends per launch
+                "timed_region": None if not alg_bytes else {
+                    "ms_per_step": round(step_s * 1e3, 4), "algorithmic_gbs": round(alg_bytes / step_s / 1e9, 1),
+                    "x_hbm_peak": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "kernel_event_ms_avg": round(avg_kernel_ms, 4) if avg_kernel_ms else None,
+                    "kernel_event_note": "HIP events around every traversal kernel of the timed region: chained launches — the first kernels of a sequence work "
+                                         "through the later batches, whose own kernels then find nothing left — so this is not a per-launch duration",
+                    "fabric_bytes_per_step_chained": pw.get("fabric_bytes_per_step_chained")},
+                # The algorithmic bytes DO pass through each CU's vector-memory return path (every node visit's 64 B, every pair's
+                # 48 B): bytes per clock per CU against the best rate a pure gather of random 64 B records reaches on this part.
+                "l1_gather": None if not (alg_bytes and ceiling) else {
+                    "isolated_launch_B_per_clk_per_CU": round(alg_bytes / (iso_ms * 1e-3) / (CUS * CU_CLOCK_HZ), 2),
+                    "timed_region_B_per_clk_per_CU": round(alg_bytes / step_s / (CUS * CU_CLOCK_HZ), 2),
+                    "steady_state_B_per_clk_per_CU": (round(alg_bytes / ((1 << 20) / (extras["batch_scaling"]["steady_state_mrays_per_s"] * 1e6)) / (CUS * CU_CLOCK_HZ), 2)
+                                                      if "batch_scaling" in extras else None),
+                    "measured_gather_ceiling_B_per_clk_per_CU": ceiling,
+                    "frac_isolated_launch": round(alg_bytes / (iso_ms * 1e-3) / (CUS * CU_CLOCK_HZ) / ceiling, 4),
+                    "frac_timed_region": round(alg_bytes / step_s / (CUS * CU_CLOCK_HZ) / ceiling, 4),
+                    "note": "256 CUs x 2.4 GHz; ceiling = tools/microbench/gather64.hip mode 2 (64 random 64 B records per wave through quad-cooperative LDS-DMA, "
+                            "6 waves/SIMD), output in %s/gather64.txt" % PROFILE_DIR},
+                "limiter": None if not pw else {k: pw.get(k) for k in (
+                    "bound", "td_busy_frac", "ta_busy_frac", "valu_busy_frac", "issue_slot_frac", "valu_lane_util", "salu_share",
+                    "l2_hit_rate", "vmem_rd_insts_per_ray", "valu_insts_per_ray", "kernel_ms_isolated")},
+                "profile_source": (prof or {}).get("source"),
+                "profile_stale": bool(prof["stale"]) if prof else None})
+            # configs[1] (coherent primaries) beside configs[2] (the headline): same definitions
+            if on_profiled_workload and args.workload == "diffuse" and "coherent_1M" in extras:
+                pc = prof.get("coherent", {})
+                by = {"configs[2] 1M first-bounce diffuse": {k: roofline.get(k) for k in ("achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel_ms_avg", "fabric_frac_of_hbm_peak", "l1_gather_frac")},
+                      "configs[1] 1M coherent primaries": core((golden.get("coherent_1M") or {}).get("bytes"), extras["coherent_1M"]["ms_per_step"], pc.get("fabric_bytes_per_launch"))}
+                for k, pk in (("configs[2] 1M first-bounce diffuse", pw), ("configs[1] 1M coherent primaries", pc)):
+                    if by[k] is not None:
+                        by[k]["limiter"] = {q: pk.get(q) for q in ("td_busy_frac", "valu_busy_frac", "valu_lane_util", "l2_hit_rate", "vmem_rd_insts_per_ray", "valu_insts_per_ray")} if pk else None
+                extras["roofline_by_config"] = by
             if prof and prof["stale"]:
                 print("bench: %s was taken with other kernel sources; re-run tools/profile_bench.sh + tools/summarize_profile.py" % PROFILE_DIR, file=sys.stderr)
 
@@ -422,7 +513,8 @@ def main():
             "higher_is_better": True, "scaling": args.mode, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("battlefield-synth (stand-in; reference scene unavailable), %d triangles, " % len(sc["indices"])) +
-                                   ("1M 1st-bounce diffuse rays per GPU per step (BASELINE configs[2]/[3]), steps issued back to back over %d engine lanes" % ctx.auto_lanes
+                                   (("1M coherent primary rays per GPU per step (BASELINE configs[1]), steps issued back to back over %d engine lanes" % ctx.auto_lanes) if args.workload == "coherent" else
+                                    "1M 1st-bounce diffuse rays per GPU per step (BASELINE configs[2]/[3]), steps issued back to back over %d engine lanes" % ctx.auto_lanes
                                     if args.mode == "weak" else "ONE 8M-ray 1st-bounce diffuse batch per step cut into %d contiguous shards (BASELINE configs[3])" % world),
                        "rays_per_gpu": n, "scene": sc["name"], "parallelism": "rays sharded x%d, scene replicated" % world,
                        "grid_blocks": launch["grid_blocks"], "waves_per_simd": launch["waves_per_simd"], "lanes": lanes,

@@ -47,8 +47,12 @@ typedef struct racc_hip_options {
                                   (≙ gpuSubmissionThreads queues, RayAccelerator.cpp:711-717); 0 => 4 */
     uint32_t waves_per_simd;   /* persistent-grid occupancy target, 1..8; 0 => engine default */
     uint32_t kernel_variant;   /* 0 => engine default (V8: reference traversal order, results bit-identical to the oracle);
-                                  45 => the 4-wide kernel (V9: same closest hit, exact-distance ties may resolve to the other
-                                  primitive; 12-20 % faster on batches below ~200k rays, slower when launches overlap); others: DESIGN.md §3, racc_hip_variant_available */
+                                  50 => the compressed 4-wide kernel (V10: 64-byte nodes, child boxes quantised conservatively to
+                                  8 bits — half the node bytes and vector-memory instructions per ray; 4-8 % faster on incoherent
+                                  batches; same closest hit except exact-distance ties and hits the reference's own box test drops
+                                  although its pair test accepts them: there the CLOSER hit, confirmed by the double-precision
+                                  arbiter, is reported); 45 => the uncompressed 4-wide kernel (V9, 128-byte nodes); others:
+                                  DESIGN.md §3, racc_hip_variant_available */
     uint32_t refill_min;       /* idle lanes that trigger a wave refill; 0 => default */
     uint32_t leaf_min;         /* leaf-holding lanes that trigger a leaf step; 0 => default */
     uint32_t chunk;            /* rays a wave dequeues per cursor atomic; 0 => default */
@@ -73,10 +77,10 @@ typedef struct racc_hip_options {
                                   kernel_variant 45.  0 => never (default) */
     uint32_t chain_launches;   /* 0/1 => device-resident batches issued on the engine's own streams (racc_hip_intersect_device with
                                   stream = NULL) are chained: waves that run out of rays in one batch go on with the next one
-                                  issued, so a sequence of batches runs like one long launch (no drain between them).  Contract:
-                                  a batch's ray and result arrays must stay untouched from the call until racc_hip_wait /
-                                  racc_hip_synchronize has returned.  2 => off: every launch stands alone, the lanes' launches
-                                  merely overlap (and an array may be reused as soon as its own lane's launch is waited for) */
+                                  issued, so a sequence of batches runs like one long launch (no drain between them).  A batch's
+                                  arrays belong to the engine until racc_hip_wait on its lane has returned and may be re-issued
+                                  at once after that (the exact rule: racc_hip_intersect_device below).  2 => off: every launch
+                                  stands alone, the lanes' launches merely overlap (same rule) */
 } racc_hip_options;
 
 typedef struct racc_hip_scene_info {
@@ -172,9 +176,27 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
  * racc_hip_synchronize then waits for all of them.
  * With stream = NULL the batch must be resident and final at the call, and — racc_hip_options::chain_launches, the default —
  * launches are CHAINED: waves of the launches issued before may start on this batch at once and carry on through it, so that
- * a sequence of batches runs like one long launch (20 batches of 1M rays back to back: 0.29 instead of 0.33 ms each).  The
- * ray and result arrays of a batch then belong to the engine until racc_hip_wait (its lane, or RACC_HIP_LANE_AUTO) returns;
- * a lane's wait returns when its batch is complete, whoever traced it.  A launch on a caller's stream is never chained. */
+ * a sequence of batches runs like one long launch (20 batches of 1M rays back to back: 0.28 instead of 0.33 ms each).  A launch
+ * on a caller's stream is never chained.
+ *
+ * Array reuse under chained launches — the exact rule (≙ the in-place, in-order ray-stream contract, RayAccelerator.h:78-83,
+ * RayAccelerator.cpp:369-410: the reference recycles a stream's arrays bounce after bounce):
+ *   - a batch's ray and result arrays belong to the engine from the call until racc_hip_wait on ITS lane (or
+ *     RACC_HIP_LANE_AUTO / racc_hip_synchronize) has returned; a lane's wait returns when its batch is complete, whoever traced it;
+ *   - after that wait the arrays may be rewritten and re-issued AT ONCE, by any means that has completed before the next call
+ *     (racc_hip_memcpy_h2d, a copy or kernel on another stream that the caller has synchronised), while the batches of the
+ *     other lanes are still in flight and their kernels go on to trace the re-issued one.
+ * Why a kernel that outlives kernel boundaries reads the NEW contents: every batch is linked into the chain by a kernel that is
+ * dispatched after the call (one thread, on the engine's control stream).  The acquire of that dispatch — ROCm gives every kernel
+ * dispatch packet an agent-scope acquire fence — makes the command processor invalidate the vector L1 of every CU and the
+ * non-coherent lines of every XCD's L2 BEFORE the kernel runs, i.e. before the link can become visible; no wave reads a batch's
+ * rays before it has seen the link (a relaxed agent-scope load, served by the L2), and nothing writes the array in between.  The
+ * ray records themselves are loaded with system-scope loads (sc0 sc1: they always miss the CU's L1), which takes the L1 out of the
+ * argument altogether.  Results travel the other way through kernel ends: a batch is complete when its own kernel and every kernel
+ * issued before it have ended (their end-of-kernel release writes the L2s back), which is what the lane's wait waits for.
+ * tests/test_gpu_reuse.py recycles three ray and three result buffers through 2,000 chained batches of 64 ... 1M rays, rewritten
+ * by host copies and by a copy kernel on another stream, on a scene that thrashes the L2s and on one that leaves them idle:
+ * every batch bit-exact. */
 int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
                               const void* d_rays, void* d_results, uint32_t count,
                               uint32_t lane, void* stream);
@@ -199,6 +221,9 @@ int racc_hip_malloc(racc_hip_ctx* ctx, uint64_t bytes, void** d_ptr);
 int racc_hip_free(racc_hip_ctx* ctx, void* d_ptr);
 int racc_hip_memcpy_h2d(racc_hip_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 int racc_hip_memcpy_d2h(racc_hip_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
+/* Device-to-device copy on `stream` (a hipStream_t as void*, e.g. from racc_hip_stream_create; NULL = the default stream): the
+ * runtime's copy kernel.  For hosts that stage ray batches in HBM and hand the engine a rotating set of arrays. */
+int racc_hip_memcpy_d2d_async(racc_hip_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes, void* stream);
 int racc_hip_synchronize(racc_hip_ctx* ctx);
 /* HIP streams for hosts that do not bring their own (passed back as the `stream` of racc_hip_intersect_device). */
 int racc_hip_stream_create(racc_hip_ctx* ctx, void** stream);

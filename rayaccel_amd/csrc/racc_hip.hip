@@ -156,7 +156,6 @@ struct racc_hip_ctx {
     std::mutex chainMutex;
     struct { const racc_hip_scene* scene = nullptr; const racc_hip_env* env = nullptr; const void* kernel = nullptr; uint32_t idx = 0; Lane* lane = nullptr; bool valid = false; } chainLast;
     bool chainEnabled = true;            // RACC_CHAIN=0 switches it off
-    uint32_t debugFlags = 0;             // RACC_DEBUG_FLAGS (A/B only): bit 0 = node records are requested for every lane, bit 1 = write-through result stores
     bool raysBypassL1 = true;            // chained kernels load rays with system-scope loads (RACC_RAY_SCOPE=0: plain loads, A/B only)
     uint32_t maxIters = 1u << 24;        // RACC_MAX_ITERS overrides (tests)
 };
@@ -550,8 +549,6 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.coopDen = 100u;
     a.leafInCpp = ctx->opts.leaf_step == 2u ? 1u : 0u;
     a.noFusedStep = ctx->opts.leaf_step == 3u ? 1u : 0u;
-    a.fetchAllLanes = ctx->debugFlags & 1u;
-    a.resultsWriteThrough = (ctx->debugFlags >> 1) & 1u;
     a.noDrainPrefetch = ctx->opts.drain_prefetch == 1u ? 0u : 1u;      // off by default: measured -3 % on a 64k-ray batch, +4..10 % on 256k-1M
     a.stats = reinterpret_cast<unsigned long long*>(lane.cursor + 8);
     // the lane's cursor / ticket / spill serve one launch at a time: a launch on another stream than the lane's previous
@@ -785,7 +782,6 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
         ctx->chainEnabled = ctx->opts.chain_launches != 2u;
         if (const char* c = std::getenv("RACC_CHAIN")) ctx->chainEnabled = std::atoi(c) != 0;
         if (const char* c = std::getenv("RACC_RAY_SCOPE")) ctx->raysBypassL1 = std::atoi(c) != 0;
-        if (const char* c = std::getenv("RACC_DEBUG_FLAGS")) ctx->debugFlags = uint32_t(std::atoi(c));
         hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&ctx->chainDev), sizeof(ChainDesc) * racc_hip_ctx::kChainRing);
         if (e1 == hipSuccess) e1 = hipMemset(ctx->chainDev, 0, sizeof(ChainDesc) * racc_hip_ctx::kChainRing);
         if (e1 == hipSuccess) {      // highest priority: a publish kernel must not wait behind the persistent waves it is meant to feed
@@ -1241,6 +1237,13 @@ int racc_hip_memcpy_d2h(racc_hip_ctx* ctx, void* dst, const void* d_src, uint64_
     if (!ctx || !dst || !d_src) return fail(RACC_HIP_ERR_INVALID, "memcpy_d2h: bad argument");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H");
+    return RACC_HIP_OK;
+}
+
+int racc_hip_memcpy_d2d_async(racc_hip_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes, void* stream) {
+    if (!ctx || !d_dst || !d_src) return fail(RACC_HIP_ERR_INVALID, "memcpy_d2d_async: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
+    HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)), "hipMemcpyAsync D2D");
     return RACC_HIP_OK;
 }
 

@@ -88,6 +88,7 @@ ABI = {
     "racc_hip_free": (_i, [_vp, _vp]),
     "racc_hip_memcpy_h2d": (_i, [_vp, _vp, _vp, _u64]),
     "racc_hip_memcpy_d2h": (_i, [_vp, _vp, _vp, _u64]),
+    "racc_hip_memcpy_d2d_async": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "racc_hip_synchronize": (_i, [_vp]),
     "racc_hip_stream_create": (_i, [_vp, _P(_vp)]),
     "racc_hip_stream_synchronize": (_i, [_vp, _vp]),

@@ -24,29 +24,27 @@ WEIGHTS = (0.16, 0.08, 0.16, 0.2, 0.14, 0.16, 0.06, 0.04)
 
 def run_reuse(ctx, scene, env, pool, ref, batches, mode, seed, max_rays=None, lanes=None, what=""):
     """Issues `batches` batches, each a random slice of `pool` copied into the rotating buffer first.  mode "h2d": the copy is
-    racc_hip_memcpy_h2d from host memory; "kernel": an elementwise kernel on a torch side stream writes the buffer from a
-    device-resident copy of the pool (synchronised before the batch is issued: a chained batch must be final at the call).
-    Returns the number of batches that were issued while another lane's batch was still in flight (an upper bound: the host
-    cannot see it exactly)."""
-    import torch
+    racc_hip_memcpy_h2d from host memory; "kernel": the runtime's device-to-device copy kernel on a side stream writes the
+    buffer from a device-resident copy of the pool (synchronised before the batch is issued: a chained batch must be final
+    at the call)."""
     rng = np.random.default_rng(seed)
     lanes = lanes or ctx.auto_lanes
     cap = min(len(pool), max_rays or len(pool))
     sizes = [s for s in SIZES if s <= cap]
     w = np.array(WEIGHTS[:len(sizes)]); w /= w.sum()
-    dev = torch.device("cuda", ctx.device)
-    bufs = [torch.empty((cap, 8), dtype=torch.int32, device=dev) for _ in range(lanes)]
-    outs = [torch.empty((cap, 4), dtype=torch.int32, device=dev) for _ in range(lanes)]
-    d_pool = torch.from_numpy(pool.view(np.int32).reshape(-1, 8)).to(dev) if mode == "kernel" else None
-    side = torch.cuda.Stream(device=dev) if mode == "kernel" else None
+    bufs = [ctx.alloc(cap * 32) for _ in range(lanes)]
+    outs = [ctx.alloc(cap * 16) for _ in range(lanes)]
+    d_pool = None
+    if mode == "kernel":
+        d_pool = ctx.alloc(pool.nbytes); d_pool.upload(pool)
+    side = ctx.create_stream() if mode == "kernel" else None
     pending = [None] * lanes       # (offset, count) of the batch in flight on each lane
     lib = ra.engine.load_library()
 
     def finish(lane):
         off, n = pending[lane]
         ctx.wait(lane)
-        got = np.empty(n, orc.RESULT_DTYPE)
-        ra.engine._check(lib.racc_hip_memcpy_d2h(ctx._h, got.ctypes.data, outs[lane].data_ptr(), got.nbytes))
+        got = outs[lane].download(orc.RESULT_DTYPE, n)
         assert_bit_exact(got, ref[off:off + n], "%s %s batch of %d rays at pool offset %d (lane %d)" % (what, mode, n, off, lane))
         pending[lane] = None
 
@@ -58,16 +56,19 @@ def run_reuse(ctx, scene, env, pool, ref, batches, mode, seed, max_rays=None, la
         off = int(rng.integers(0, len(pool) - n + 1))
         if mode == "h2d":
             src = np.ascontiguousarray(pool[off:off + n])
-            ra.engine._check(lib.racc_hip_memcpy_h2d(ctx._h, bufs[lane].data_ptr(), src.ctypes.data, src.nbytes))
-        else:
-            with torch.cuda.stream(side):
-                torch.bitwise_or(d_pool[off:off + n], 0, out=bufs[lane][:n])
-            side.synchronize()
-        ctx.intersect_device(scene, env, bufs[lane].data_ptr(), outs[lane].data_ptr(), n, lane=lane)
+            ra.engine._check(lib.racc_hip_memcpy_h2d(ctx._h, bufs[lane].ptr, src.ctypes.data, src.nbytes))
+        else:       # the runtime's device-to-device copy kernel on a side stream, synchronised before the batch is issued
+            ra.engine._check(lib.racc_hip_memcpy_d2d_async(ctx._h, bufs[lane].ptr, d_pool.ptr + off * 32, n * 32, side))
+            ctx.stream_synchronize(side)
+        ctx.intersect_device(scene, env, bufs[lane].ptr, outs[lane].ptr, n, lane=lane)
         pending[lane] = (off, n)
     for lane in range(lanes):
         if pending[lane] is not None:
             finish(lane)
+    for b in bufs + outs + ([d_pool] if d_pool else []):
+        b.free()
+    if side:
+        ctx.destroy_stream(side)
 
 
 def _pool_small(small):

@@ -2,24 +2,46 @@
 # rocprofv3 passes over bench.py (run on the GPU box).  --kernel-trace/--stats and each --pmc set are SEPARATE runs (never
 # combined with sys/hip/hsa traces); every pass has its own timeout (a counter set the hardware cannot collect makes
 # rocprofv3 abort and then hang).  Usage: tools/profile_bench.sh <tag>      then: python tools/summarize_profile.py <tag>
-TAG=${1:-r02}
+# Passes:
+#   stats                 the bench command as the driver runs it (chained launches over the lanes): kernel trace + stats
+#   stats_one_lane[_X]    the same with one lane and no chaining (every kernel alone, one batch each); X = coherent: configs[1]'s batch; v10: kernel_variant 50
+#   pmc_<i>               one counter set per pass, diffuse batch, one lane, no chaining: counters describe ONE launch of ONE batch alone on the GPU
+#   pmcc_<i>              the same for the coherent primary batch (--workload coherent), fewer sets
+#   pmcv_<i>              the same for the compressed 4-wide kernel (kernel_variant 50), diffuse batch, fewer sets
+#   pmcx_<i>              FETCH_SIZE / WRITE_SIZE in the timed region's own mode (three lanes, chained); rocprofv3 serialises dispatches under --pmc
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 CMD="python $REPO/bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 3"
-# (1) the bench command as the driver runs it (chained launches over the lanes) and (2) the same with one lane and no chaining (every kernel alone, one batch each)
+ONE='{"lanes":1,"chain_launches":2}'
+V10='{"lanes":1,"chain_launches":2,"kernel_variant":50}'
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1
-timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_lane" -- $CMD --engine-opts '{"lanes":1,"chain_launches":2}' > "$OUT/stats_one_lane.log" 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_lane" -- $CMD --engine-opts "$ONE" > "$OUT/stats_one_lane.log" 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_lane_coherent" -- $CMD --workload coherent --engine-opts "$ONE" > "$OUT/stats_one_lane_coherent.log" 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_lane_v10" -- $CMD --engine-opts "$V10" > "$OUT/stats_one_lane_v10.log" 2>&1
+pass() {   # pass <dir prefix> <index> "<counters>" <extra bench args...>
+  local pre=$1 i=$2 set=$3; shift 3
+  timeout -k 5 240 rocprofv3 --pmc $set --output-format csv -d "$OUT/${pre}_$i" -- $CMD "$@" > "$OUT/${pre}_$i.log" 2>&1 || echo "pass ${pre}_$i ($set) failed"
+}
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \
            "GRBM_GUI_ACTIVE GRBM_COUNT" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "TA_TA_BUSY_sum TD_TD_BUSY_sum" "TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum"; do
-  i=$((i+1))
-  # counters describe ONE launch of ONE batch alone on the GPU with its full grid: one engine lane, launches not chained (rocprofv3 serialises dispatches for --pmc anyway)
-  timeout -k 5 240 rocprofv3 --pmc $set --output-format csv -d "$OUT/pmc_$i" -- $CMD --engine-opts '{"lanes":1,"chain_launches":2}' > "$OUT/pmc_$i.log" 2>&1 || echo "pass $i ($set) failed"
+  i=$((i+1)); pass pmc $i "$set" --engine-opts "$ONE"
+done
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_INSTS_VMEM_WR" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY" "GRBM_GUI_ACTIVE GRBM_COUNT" "TA_TA_BUSY_sum TD_TD_BUSY_sum"; do
+  i=$((i+1)); pass pmcc $i "$set" --workload coherent --engine-opts "$ONE"
+  pass pmcv $i "$set" --engine-opts "$V10"
+done
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1)); pass pmcx $i "$set"
 done
 find "$OUT" -name "*.csv" | wc -l
 du -sh "$OUT"

@@ -11,7 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CUS, SIMDS, XCDS = 256, 1024, 8
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
@@ -36,65 +36,107 @@ def trace_durations(sub):
                       grid=rows[4].get("Grid_Size"), workgroup=rows[4].get("Workgroup_Size"))
 
 
+def counters(prefix, sum_timed=False):
+    """Mean over the 20 timed launches (dispatches 4..23 among the traversal kernels) of every counter of the passes <prefix>_<i>;
+    sum_timed: the SUM over those dispatches / 20 (chained launches: one kernel may do several batches' work, the others none)."""
+    res = {}
+    for d in sorted(filter(None, (newest(os.path.join(p, "*", "*_counter_collection.csv")) for p in glob.glob(os.path.join(src, prefix + "_[0-9]*"))))):
+        byc = collections.defaultdict(list)
+        for r in csv.DictReader(open(d)):
+            if "traverseKernel" in r["Kernel_Name"]:
+                byc[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+        for k, v in byc.items():
+            v.sort()
+            vals = [x[1] for x in v]
+            res[k] = dict(mean_timed=(float(np.sum(vals[4:24])) / 20.0 if sum_timed else float(np.mean(vals[4:24]))), launches=len(vals))
+    return res
+
+
+def derive(c, trace, rays=1 << 20):
+    """The figures bench.py reports for one (kernel, batch) pair from its isolated PMC passes and its one-lane kernel trace."""
+    g = lambda k: c.get(k, {}).get("mean_timed")
+    cycles = g("GRBM_GUI_ACTIVE") / XCDS if g("GRBM_GUI_ACTIVE") else None          # the counter sums the 8 XCDs
+    der = dict(kernel=(trace or {}).get("kernel"), kernel_ms_isolated=(trace or {}).get("timed_mean_ms"), kernel_cycles_isolated=cycles)
+    if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+        der["fabric_bytes_per_launch"] = int(2 * g("FETCH_SIZE") * 1024.0 + g("WRITE_SIZE") * 1024.0)
+        der["fetch_bytes_per_launch"] = int(2 * g("FETCH_SIZE") * 1024.0)
+        der["write_bytes_per_launch"] = int(g("WRITE_SIZE") * 1024.0)
+        der["write_x_compulsory"] = round(g("WRITE_SIZE") * 1024.0 / (rays * 16.0), 2)
+        if der["kernel_ms_isolated"]:
+            der["fabric_frac_of_hbm_peak_isolated"] = round(der["fabric_bytes_per_launch"] / (der["kernel_ms_isolated"] * 1e-3) / 8e12, 4)
+    if cycles:
+        if g("TD_TD_BUSY_sum"): der["td_busy_frac"] = round(g("TD_TD_BUSY_sum") / (CUS * cycles), 4)
+        if g("TA_TA_BUSY_sum"): der["ta_busy_frac"] = round(g("TA_TA_BUSY_sum") / (CUS * cycles), 4)
+        if g("SQ_ACTIVE_INST_VALU"): der["valu_busy_frac"] = round(4 * g("SQ_ACTIVE_INST_VALU") / (SIMDS * cycles), 4)
+        if g("SQ_ACTIVE_INST_ANY"): der["issue_slot_frac"] = round(4 * g("SQ_ACTIVE_INST_ANY") / (SIMDS * cycles), 4)
+    if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
+        der["valu_lane_util"] = round(g("SQ_THREAD_CYCLES_VALU") / (64 * g("SQ_ACTIVE_INST_VALU")), 4)
+    insts = [g(k) or 0.0 for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM")]
+    if g("SQ_INSTS_SALU") and sum(insts):
+        der["salu_share"] = round(g("SQ_INSTS_SALU") / sum(insts), 4)
+        der["valu_insts_per_ray"] = round(g("SQ_INSTS_VALU") / rays, 2)
+        der["vmem_rd_insts_per_ray"] = round(g("SQ_INSTS_VMEM_RD") / rays, 3)
+    for k in ("SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU", "TD_TD_BUSY_sum"):
+        if g(k): der[k + "_per_launch"] = g(k)
+    if g("TCC_HIT_sum") and g("TCC_MISS_sum"):
+        der["l2_hit_rate"] = round(g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")), 4)
+    busiest = max(((der.get(k) or 0.0, k) for k in ("td_busy_frac", "ta_busy_frac", "valu_busy_frac")), default=(0, None))
+    names = dict(td_busy_frac="TD (vector-memory data-return path of the CU)", ta_busy_frac="TA (vector-memory address path of the CU)", valu_busy_frac="VALU issue")
+    der["bound"] = "%s: busy %.0f %% of the launch, drain included" % (names.get(busiest[1], "?"), 100 * busiest[0]) if busiest[0] else None
+    return der
+
+
 out = {}
-for sub, name in (("stats", "kernel_stats.csv"), ("stats_one_lane", "kernel_stats_one_lane.csv")):
-    s = newest(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
-    if s:
-        shutil.copy(s, os.path.join(dst, name))
+for sub, name in (("stats", "kernel_stats.csv"), ("stats_one_lane", "kernel_stats_one_lane.csv"), ("stats_one_lane_coherent", "kernel_stats_one_lane_coherent.csv"),
+                  ("stats_one_lane_v10", "kernel_stats_one_lane_v10.csv")):
+    s_ = newest(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
+    if s_:
+        shutil.copy(s_, os.path.join(dst, name))
 _, out["kernel_trace"] = trace_durations("stats")
-_, out["kernel_trace_one_lane"] = trace_durations("stats_one_lane")
-for d in sorted(filter(None, (newest(os.path.join(p, "*", "*_counter_collection.csv")) for p in glob.glob(os.path.join(src, "pmc_*"))))):   # newest run of every pass
-    byc = collections.defaultdict(list)
-    for r in csv.DictReader(open(d)):
-        if "traverseKernel" in r["Kernel_Name"]:
-            byc[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
-    for k, v in byc.items():
-        v.sort()
-        vals = [x[1] for x in v]
-        out[k] = dict(mean_timed_diffuse=float(np.mean(vals[4:24])), launches=len(vals))
+traces = {k: trace_durations(sub)[1] for k, sub in (("diffuse", "stats_one_lane"), ("coherent", "stats_one_lane_coherent"), ("v10_diffuse", "stats_one_lane_v10"))}
+out["kernel_trace_one_lane"] = traces
+pm = {"diffuse": counters("pmc"), "coherent": counters("pmcc"), "v10_diffuse": counters("pmcv"), "diffuse_chained": counters("pmcx", sum_timed=True)}
+out["counters"] = pm
 h = hashlib.sha256()
 for rel in ("rayaccel_amd/csrc/racc_kernel_v8.inc", "rayaccel_amd/csrc/racc_device.inc"):
     h.update(open(os.path.join(ROOT, rel), "rb").read())
 out["kernel_source_sha256"] = h.hexdigest()
+out["kernel_v10_source_sha256"] = hashlib.sha256(open(os.path.join(ROOT, "rayaccel_amd/csrc/racc_kernel_v10.inc"), "rb").read()).hexdigest()
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 
-g = lambda k: out.get(k, {}).get("mean_timed_diffuse")
-cycles = g("GRBM_GUI_ACTIVE") / XCDS if g("GRBM_GUI_ACTIVE") else None          # the counter sums the 8 XCDs
-one = out.get("kernel_trace_one_lane") or {}
-der = dict(kernel_source_sha256=out["kernel_source_sha256"], source="%s/pmc_summary.json (rocprofv3 --pmc, one counter set per pass) + kernel_stats*.csv" % os.path.relpath(dst, ROOT),
+der = dict(kernel_source_sha256=out["kernel_source_sha256"], kernel_v10_source_sha256=out["kernel_v10_source_sha256"],
+           source="%s/pmc_summary.json (rocprofv3 --pmc, one counter set per pass, the kernel alone on the GPU: one lane, no chaining) + kernel_stats*.csv" % os.path.relpath(dst, ROOT),
            kernel=(out.get("kernel_trace") or {}).get("kernel"),
            kernel_ms_overlapped=(out.get("kernel_trace") or {}).get("timed_mean_ms"),
            ms_per_launch_overlapped=(out.get("kernel_trace") or {}).get("timed_span_ms_per_launch"),
-           kernel_ms_isolated=one.get("timed_mean_ms"), kernel_cycles_isolated=cycles,
            formulas=dict(
-               hbm_bytes_per_launch="2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024   (gfx950 tallies 128 B fetches at 64 B: MI355X_MICROARCH.md, HBM section)",
-               hbm_physical_frac_isolated="hbm_bytes_per_launch / kernel_ms_isolated / 8 TB/s",
+               fabric_bytes_per_launch="2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024   (gfx950 tallies 128 B fetches at 64 B: MI355X_MICROARCH.md, HBM section); L2-miss traffic, Infinity-Cache hits included",
+               fabric_frac_of_hbm_peak_isolated="fabric_bytes_per_launch / kernel_ms_isolated / 8 TB/s",
+               write_x_compulsory="WRITE_SIZE * 1024 / (16 B x rays)",
                td_busy_frac="TD_TD_BUSY_sum / (256 CUs * GRBM_GUI_ACTIVE / 8 XCDs)",
                ta_busy_frac="TA_TA_BUSY_sum / (256 CUs * cycles)",
                valu_busy_frac="4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * cycles)   (the counter is in quad-cycles)",
                issue_slot_frac="4 * SQ_ACTIVE_INST_ANY / (1024 SIMDs * cycles)",
                valu_lane_util="SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)",
                salu_share="SQ_INSTS_SALU / (SQ_INSTS_VALU + SQ_INSTS_SALU + SQ_INSTS_VMEM_RD + SQ_INSTS_VMEM_WR + SQ_INSTS_LDS + SQ_INSTS_SMEM)",
-               l2_hit_rate="TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)"))
-if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
-    der["hbm_bytes_per_launch"] = int(2 * g("FETCH_SIZE") * 1024.0 + g("WRITE_SIZE") * 1024.0)
-    if one.get("timed_mean_ms"):
-        der["hbm_physical_frac_isolated"] = round(der["hbm_bytes_per_launch"] / (one["timed_mean_ms"] * 1e-3) / 8e12, 4)
-if cycles:
-    if g("TD_TD_BUSY_sum"): der["td_busy_frac"] = round(g("TD_TD_BUSY_sum") / (CUS * cycles), 4)
-    if g("TA_TA_BUSY_sum"): der["ta_busy_frac"] = round(g("TA_TA_BUSY_sum") / (CUS * cycles), 4)
-    if g("SQ_ACTIVE_INST_VALU"): der["valu_busy_frac"] = round(4 * g("SQ_ACTIVE_INST_VALU") / (SIMDS * cycles), 4)
-    if g("SQ_ACTIVE_INST_ANY"): der["issue_slot_frac"] = round(4 * g("SQ_ACTIVE_INST_ANY") / (SIMDS * cycles), 4)
-if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
-    der["valu_lane_util"] = round(g("SQ_THREAD_CYCLES_VALU") / (64 * g("SQ_ACTIVE_INST_VALU")), 4)
-insts = [g(k) or 0.0 for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM")]
-if g("SQ_INSTS_SALU") and sum(insts):
-    der["salu_share"] = round(g("SQ_INSTS_SALU") / sum(insts), 4)
-    der["valu_insts_per_ray"] = round(g("SQ_INSTS_VALU") / (1 << 20), 1)
-if g("TCC_HIT_sum") and g("TCC_MISS_sum"):
-    der["l2_hit_rate"] = round(g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")), 4)
-busiest = max(((der.get(k) or 0.0, k) for k in ("td_busy_frac", "ta_busy_frac", "valu_busy_frac")), default=(0, None))
-names = dict(td_busy_frac="TD (vector-memory data-return path of the CU)", ta_busy_frac="TA (vector-memory address path of the CU)", valu_busy_frac="VALU issue")
-der["bound"] = "%s: busy %.0f %% of the launch, drain included" % (names.get(busiest[1], "?"), 100 * busiest[0]) if busiest[1] else None
+               l2_hit_rate="TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)",
+               vmem_rd_insts_per_ray="SQ_INSTS_VMEM_RD / 2^20 rays (wave-level instructions)",
+               fabric_bytes_per_step_chained="(2 * sum FETCH_SIZE + sum WRITE_SIZE) * 1024 over the traversal dispatches of the 20 timed steps / 20, three lanes, chained (rocprofv3 serialises dispatches under --pmc)"))
+for key in ("diffuse", "coherent", "v10_diffuse"):
+    der[key] = derive(pm[key], traces.get(key))
+cx = pm["diffuse_chained"]
+if cx.get("FETCH_SIZE") and cx.get("WRITE_SIZE"):
+    der["diffuse"]["fabric_bytes_per_step_chained"] = int((2 * cx["FETCH_SIZE"]["mean_timed"] + cx["WRITE_SIZE"]["mean_timed"]) * 1024.0)
+d0, d1 = der["diffuse"], der["v10_diffuse"]
+if d0.get("SQ_INSTS_VMEM_RD_per_launch") and d1.get("SQ_INSTS_VMEM_RD_per_launch"):
+    der["v10_vs_default"] = dict(vmem_rd_insts=round(d1["SQ_INSTS_VMEM_RD_per_launch"] / d0["SQ_INSTS_VMEM_RD_per_launch"], 3),
+                                 td_busy_cycles=round(d1["TD_TD_BUSY_sum_per_launch"] / d0["TD_TD_BUSY_sum_per_launch"], 3) if d0.get("TD_TD_BUSY_sum_per_launch") and d1.get("TD_TD_BUSY_sum_per_launch") else None,
+                                 valu_insts=round(d1["SQ_INSTS_VALU_per_launch"] / d0["SQ_INSTS_VALU_per_launch"], 3),
+                                 kernel_ms=round(d1["kernel_ms_isolated"] / d0["kernel_ms_isolated"], 3) if d0.get("kernel_ms_isolated") and d1.get("kernel_ms_isolated") else None)
+# copies of the microbenchmark outputs taken on the same box (tools/microbench/run_microbench.sh <tag>)
+mb = os.path.join(ROOT, "gpurun_out", "microbench_" + tag)
+for f in ("gather64.txt", "gather128.txt", "scatter16.txt", "microbench.json"):
+    if os.path.exists(os.path.join(mb, f)):
+        shutil.copy(os.path.join(mb, f), os.path.join(dst, f))
 json.dump(der, open(os.path.join(dst, "derived.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in der.items() if k != "formulas"}, indent=1))
