@@ -184,6 +184,14 @@ def main():
             return []
         return [t for lane in range(lanes) for t in ctx.kernel_times(lane)]
 
+    # The traversal kernel alone on the GPU, one launch at a time (HIP events around the kernel on the stream it is launched on):
+    # the launch duration `roofline.achieved` is computed from — in the timed region launches are chained, a kernel there either
+    # works through many batches or finds nothing left, so no per-launch duration exists.  Untimed, a few ms, before the warm-up.
+    iso_ms = None
+    if rank == 0:
+        ctx.intersect_device_timed(scene, env, d_rays.data_ptr(), outs[-1].data_ptr(), n, 2)
+        iso_ms = float(np.mean(ctx.intersect_device_timed(scene, env, d_rays.data_ptr(), outs[-1].data_ptr(), n, 10)))
+
     if args.warmup:
         run_overlapped(args.warmup)
     drain_kernel_times()
@@ -207,14 +215,6 @@ def main():
 
     value = total_rays * args.steps / elapsed / 1e6
     launch = ctx.launch_info()
-    # The traversal kernel alone on the GPU, one launch at a time (HIP events around the kernel on the stream it is launched on):
-    # the launch duration `roofline.achieved` is computed from — in the timed region launches are chained, a kernel there either
-    # works through many batches or finds nothing left, so no per-launch duration exists.  Untimed, a few ms.
-    iso_ms = None
-    if rank == 0:
-        ctx.intersect_device_timed(scene, env, d_rays.data_ptr(), outs[-1].data_ptr(), n, 2)
-        iso_ms = float(np.mean(ctx.intersect_device_timed(scene, env, d_rays.data_ptr(), outs[-1].data_ptr(), n, 10)))
-
     d_ref_bits = d_out.view(torch.int32).clone()      # the default kernel's records of the timed batch (the extras reuse the result arrays)
 
     # ---- optional extras, all outside the timed region ------------------------------------------
