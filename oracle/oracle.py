@@ -58,6 +58,8 @@ def lib():
         _lib.orc_brute_closest.restype = None
         _lib.orc_brute_one.argtypes = [vp, vp, u32, vp, vp, vp, vp]
         _lib.orc_brute_one.restype = C.c_int
+        _lib.orc_pt_sample_material.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
+        _lib.orc_pt_sample_material.restype = C.c_int
     return _lib
 
 
@@ -170,3 +172,14 @@ def algorithmic_bytes(results, nv, npairs):
     """B(ray) = 32 + 16 + 64*Nv + 48*Np + 4*[hit]."""
     hit = (results["triangle"] != 0xFFFFFFFF).astype(np.int64)
     return 48 * len(results) + 64 * int(nv.astype(np.int64).sum()) + 48 * int(npairs.astype(np.int64).sum()) + 4 * int(hit.sum())
+
+
+def pt_sample_material(ke, rnd, normal, wo, exact_trig=False):
+    """One lane of ReflectiveDiffuseMaterial::sample8 (Renderer/Materials.cpp:39-151) per sample -> (wi[n,3], colour[n,3], diffuse[n])."""
+    ke = np.ascontiguousarray(ke, np.float32)
+    rnd, normal, wo = (np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in (rnd, normal, wo))
+    n = len(rnd)
+    wi, colour, diffuse = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
+    for i in range(n):
+        diffuse[i] = lib().orc_pt_sample_material(_p(ke), _p(rnd[i]), _p(normal[i]), _p(wo[i]), 1 if exact_trig else 0, _p(wi[i]), _p(colour[i]))
+    return wi, colour, diffuse

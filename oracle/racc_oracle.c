@@ -642,3 +642,68 @@ void orc_brute_closest(const float* vertices, const uint32_t* indices, uint32_t 
         if (t2) t2[i] = st;
     }
 }
+
+/* ======================================================================================================================
+ * Path-tracing consumer: scalar restatement of the reference's material sampling, one lane of
+ * ReflectiveDiffuseMaterial::sample8 (Renderer/Materials.cpp:39-151) with its own sine / cosine approximations
+ * (Materials.cpp:11-29), operation by operation: _mm256_fmadd_ps -> fmaf, _mm256_fmsub_ps(a,b,c) -> fmaf(a,b,-c),
+ * blendv(a,b,m) -> sign bit of m picks b.  The two hardware approximations the reference uses, _mm256_rcp_ps and
+ * _mm256_rsqrt_ps (12-bit, implementation defined), are evaluated exactly here (1/x, 1/sqrt(x)).  Test infrastructure:
+ * tests/test_host_build.py holds the product's scalar re-derivation (rayaccel_amd/csrc/pt_shade.h sampleMaterial) to this.
+ * exact_trig != 0 replaces the reference's parabola sine/cosine (|error| up to 0.056) by sin/cos of 2*pi*r: pt_shade.h
+ * deliberately uses exact values there, so the comparison is tight with the flag and loose (the parabola's error) without.
+ * ====================================================================================================================== */
+static float pt_sin_approx(float x) {                      /* Materials.cpp:11-22: sin(2 pi x), x in [0,1) */
+    const float y = fmaf(-16.0f, x, 8.0f);
+    const int gt = x >= 0.5f;
+    float xy = x * y;
+    const float z = gt ? y : 0.0f;
+    if (gt) xy = -xy;
+    return xy + z;
+}
+static float pt_cos_approx(float x) {                      /* Materials.cpp:24-28 */
+    const float y = x - 0.75f;
+    x = signbit(y) ? x + 0.25f : y;                        /* blendv(y, x + 0.25, y): sign of y picks x + 0.25 */
+    return pt_sin_approx(x);
+}
+
+/* ke = {kd.r, kd.g, kd.b, eta} (Materials.cpp:32-37); rnd, normal, wo: 3 floats each; out: wi[3], colour[3]; returns 1 if the
+ * diffuse direction was chosen (the mask of Materials.cpp:128). */
+int orc_pt_sample_material(const float* ke, const float* rnd, const float* normal, const float* wo, int exact_trig, float* wi, float* colour) {
+    const float nx = normal[0], ny = normal[1], nz = normal[2];
+    float cosi = fmaf(nz, wo[2], fmaf(ny, wo[1], nx * wo[0]));                     /* :57 */
+    cosi = cosi > 0.0f ? cosi : 0.0f;                                              /* :58 (max_ps(cosi, 0): NaN -> 0) */
+    const float two_cosi = 2.0f * cosi;
+    const float rx = fmaf(two_cosi, nx, -wo[0]), ry = fmaf(two_cosi, ny, -wo[1]), rz = fmaf(two_cosi, nz, -wo[2]);   /* :60-62 */
+    const float eta = ke[3];
+    const float cosi2_minus_one = fmaf(cosi, cosi, -1.0f);                         /* :67 */
+    const float eta2 = eta * eta;
+    const float k = fmaf(eta2, cosi2_minus_one, 1.0f);                             /* :69 */
+    const float cost = sqrtf(k);                                                   /* :70 (NaN for k < 0: blended away below) */
+    const float rper = fmaf(eta, cosi, -cost) * (1.0f / fmaf(eta, cosi, cost));    /* :74 */
+    const float rpar = -(fmaf(eta, cost, -cosi) * (1.0f / fmaf(eta, cost, cosi))); /* :75 */
+    float fresnel = 0.5f * fmaf(rpar, rpar, rper * rper);                          /* :77-78 */
+    if (signbit(k)) fresnel = 1.0f;                                                /* :79 */
+    const int baseMask = !(fabsf(nx) <= 0.1f);                                     /* :82-83 (_CMP_NLE_US) */
+    float ux = baseMask ? -nz : 0.0f, uy = baseMask ? 0.0f : -nz, uz = baseMask ? nx : ny;     /* :85-88 */
+    const float fb = 1.0f / sqrtf(fmaf(uz, uz, fmaf(uy, uy, ux * ux)));            /* :90 */
+    ux *= fb; uy *= fb; uz *= fb;
+    const float vx = fmaf(ny, uz, -(nz * uy)), vy = fmaf(nz, ux, -(nx * uz)), vz = fmaf(nx, uy, -(ny * ux));          /* :96-98 */
+    float sinX, cosX;
+    if (exact_trig) { sinX = (float)sin(6.283185307179586 * (double)rnd[0]); cosX = (float)cos(6.283185307179586 * (double)rnd[0]); }
+    else { sinX = pt_sin_approx(rnd[0]); cosX = pt_cos_approx(rnd[0]); }           /* :100-101 */
+    const float r2 = rnd[1], r2s = sqrtf(r2), sq1 = sqrtf(1.0f - r2);              /* :103-106 */
+    float dx = fmaf(nx, sq1, fmaf(ux, cosX, vx * sinX) * r2s);                     /* :108-110 */
+    float dy = fmaf(ny, sq1, fmaf(uy, cosX, vy * sinX) * r2s);
+    float dz = fmaf(nz, sq1, fmaf(uz, cosX, vz * sinX) * r2s);
+    const float fd = 1.0f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));            /* :112 */
+    dx *= fd; dy *= fd; dz *= fd;
+    float r = ke[0], g = ke[1], b = ke[2];
+    const float s0 = fresnel * 3.0f, s1 = b + (r + g), sum = s0 + s1;              /* :123-125 */
+    const int mask = rnd[2] * sum >= s0;                                           /* :127-128 (_CMP_GE_OQ) */
+    wi[0] = mask ? dx : rx; wi[1] = mask ? dy : ry; wi[2] = mask ? dz : rz;        /* :130-132 */
+    if (!mask) r = g = b = fresnel;                                                /* :134-136 */
+    const float scale = sum * (1.0f / (b + (r + g)));                              /* :138 */
+    colour[0] = r * scale; colour[1] = g * scale; colour[2] = b * scale;
+    return mask;
+}

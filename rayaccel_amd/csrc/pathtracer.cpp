@@ -134,6 +134,18 @@ struct Renderer {
 extern "C" void racc_pt_test_sincos2pi(const float* r, uint32_t n, float* s, float* c) {
     for (uint32_t i = 0; i < n; ++i) ptshade::sincos2pi(r[i], s[i], c[i]);
 }
+// Test hook: ptshade::sampleMaterial on n samples (kd[3] + eta per sample-independent material; rnd/normal/wo: 3 floats per sample).
+extern "C" void racc_pt_test_sample_material(const float* ke, const float* rnd, const float* normal, const float* wo, uint32_t n,
+                                             float* wi, float* colour, int* alive) {
+    ptshade::Materials mat{};
+    for (int m = 0; m < 4; ++m) { mat.kd[m][0] = ke[0]; mat.kd[m][1] = ke[1]; mat.kd[m][2] = ke[2]; mat.eta[m] = ke[3]; }
+    for (uint32_t i = 0; i < n; ++i) {
+        ptshade::Vec w{0.f, 0.f, 0.f};
+        alive[i] = ptshade::sampleMaterial(mat, 0, ptshade::Vec{normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]}, ptshade::Vec{wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]},
+                                           rnd[3 * i], rnd[3 * i + 1], rnd[3 * i + 2], w, colour + 3 * i) ? 1 : 0;
+        wi[3 * i] = w.x; wi[3 * i + 1] = w.y; wi[3 * i + 2] = w.z;
+    }
+}
 extern "C" void racc_pt_test_uniform(uint32_t pixel, uint32_t sample, uint32_t depth, uint32_t stream, uint32_t n, float* out) {
     for (uint32_t i = 0; i < n; ++i) out[i] = ptshade::uniformKeyed(ptshade::pathKey(pixel + i, sample), depth, stream);
 }

@@ -120,3 +120,41 @@ def test_non_finite_vertices_are_refused(small_scene):
         v[17, 1] = bad
         with pytest.raises(ra.RaccError):
             ra.HostScene(v, small_scene["indices"])
+
+
+def test_material_sampling_matches_the_reference_restatement():
+    """the path-tracing consumer's BSDF sampling (pt_shade.h sampleMaterial, a scalar re-derivation) held to the
+    oracle's operation-by-operation restatement of the reference's ReflectiveDiffuseMaterial::sample8 (Renderer/Materials.cpp:39-151):
+    the same choice between mirror and diffuse direction, the same colour weights, the same mirror direction, the same diffuse
+    direction when both use exact sine/cosine — and a diffuse direction within the error of the reference's own parabola
+    sine/cosine (Materials.cpp:11-29, up to 0.056) otherwise: that substitution is pt_shade.h's one deliberate deviation."""
+    import ctypes as C
+    from rayaccel_amd import engine
+    from oracle import oracle as orc
+    engine.load_library()
+    lib = C.CDLL(engine.PT_LIB_PATH)
+    rng = np.random.default_rng(17)
+    n = 20000
+    normal = rng.normal(size=(n, 3)).astype(np.float32)
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True).astype(np.float32)
+    wo = rng.normal(size=(n, 3)).astype(np.float32)
+    wo /= np.linalg.norm(wo, axis=1, keepdims=True).astype(np.float32)
+    flip = (normal * wo).sum(1) < 0          # the consumer hands the material a normal on the viewer's side (PathTracingRenderer.cpp:230-260)
+    normal[flip] *= -1
+    rnd = rng.random((n, 3), dtype=np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for ke in ([0.6, 0.5, 0.4, 1.5], [0.9, 0.9, 0.9, 1.0 / 1.5], [0.05, 0.1, 0.7, 2.4]):        # kd + eta (Renderer/main.cpp:165-168 style; eta < 1: total internal reflection occurs)
+        ke = np.array(ke, np.float32)
+        wi, col, alive = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
+        lib.racc_pt_test_sample_material(vp(ke), vp(rnd), vp(normal), vp(wo), C.c_uint32(n), vp(wi), vp(col), vp(alive))
+        assert alive.all()
+        wi_e, col_e, dif_e = orc.pt_sample_material(ke, rnd, normal, wo, exact_trig=True)
+        wi_a, col_a, dif_a = orc.pt_sample_material(ke, rnd, normal, wo, exact_trig=False)
+        assert np.array_equal(dif_e, dif_a)                              # the choice does not depend on the trig functions
+        np.testing.assert_allclose(col, col_e, rtol=2e-4, atol=1e-6)      # colour weights: Materials.cpp:121-141 (Fresnel near grazing incidence cancels: 1e-4)
+        np.testing.assert_allclose(wi, wi_e, rtol=0, atol=3e-6)           # mirror direction and exact-trig diffuse direction
+        refl = dif_e == 0
+        assert 0.02 < refl.mean() < 0.98 or ke[3] < 1.0
+        np.testing.assert_allclose(wi[refl], wi_a[refl], rtol=0, atol=3e-6)
+        cosang = np.clip((wi[~refl].astype(np.float64) * wi_a[~refl]).sum(1), -1, 1)
+        assert np.degrees(np.arccos(cosang)).max() < 4.0                  # the reference's parabola sine/cosine: <= 0.056 off before normalisation
