@@ -7,7 +7,7 @@ import rayaccel_amd as ra
 from rayaccel_amd import synth
 from oracle import oracle as orc
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from helpers import WIDE_VARIANTS, assert_bit_exact, assert_same_closest_hit        # hits bit for bit (wide kernels: up to exact-distance ties), miss colours (acosf: libm vs ocml) to 1e-5
+from helpers import QUANT_VARIANTS, WIDE_VARIANTS, assert_bit_exact, assert_same_closest_hit        # hits bit for bit (wide kernels: up to exact-distance ties), miss colours (acosf: libm vs ocml) to 1e-5
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -21,7 +21,7 @@ pool = pool[rng.permutation(len(pool))]
 ref_pool = orc.traverse(blobs, pool, env=sc["env"], threads=8)
 bad = 0
 for rnd in range(rounds):
-    opt = dict(kernel_variant=int(rng.choice([0, 0, 0, 41, 43, 45, 45, 46, 49] + [v for v in (22, 23, 24, 17, 11, 1, 31, 34, 38) if v in ra.engine.available_variants()])), lanes=int(rng.integers(1, 5)))
+    opt = dict(kernel_variant=int(rng.choice([0, 0, 0, 41, 43, 45, 46, 49, 50, 50, 50, 51, 53] + [v for v in (22, 23, 24, 17, 11, 1, 31, 34, 38) if v in ra.engine.available_variants()])), lanes=int(rng.integers(1, 5)))
     if rng.random() < 0.6:
         opt.update(waves_per_simd=int(rng.integers(1, 9)), refill_min=int(rng.integers(1, 65)), leaf_min=int(rng.integers(1, 65)),
                    chunk=int(rng.choice([1, 7, 32, 64, 100, 128, 1000])), tail_active=int(rng.integers(1, 70)),
@@ -31,16 +31,39 @@ for rnd in range(rounds):
         env = ctx.create_environment(sc["env"])
         errs = []
 
+        chained = bool(rng.random() < 0.4)
+
+        def check(got, off, n, rays, lane):
+            v = opt["kernel_variant"]
+            try:
+                if v in QUANT_VARIANTS:
+                    assert_same_closest_hit(got, ref_pool[off:off + n], arbiter=dict(vertices=sc["vertices"], indices=sc["indices"], rays=rays))
+                elif v in WIDE_VARIANTS:
+                    assert_same_closest_hit(got, ref_pool[off:off + n])
+                else:
+                    assert_bit_exact(got, ref_pool[off:off + n])
+            except AssertionError as e:
+                errs.append((lane, n, off, str(e)[:160]))
+
         def work(lane, seed):
             r2 = np.random.default_rng(seed)
+            pending = []
             for _ in range(4):                                      # back-to-back launches of different sizes on one lane
                 n = int(r2.choice([1, 2, 63, 64, 65, 255, 4097, int(r2.integers(1, 1 << 14)), int(r2.integers(1, len(pool) - 1))]))
                 off = int(r2.integers(0, len(pool) - n + 1))
-                got = ctx.intersect(scene, env, np.ascontiguousarray(pool[off:off + n]), lane=lane)
-                try:
-                    (assert_same_closest_hit if opt["kernel_variant"] in WIDE_VARIANTS else assert_bit_exact)(got, ref_pool[off:off + n])
-                except AssertionError as e:
-                    errs.append((lane, n, off, str(e)[:120]))
+                rays = np.ascontiguousarray(pool[off:off + n])
+                if chained:                                         # device-resident, engine's own streams: chained launches, lanes rotated
+                    d_r = ctx.alloc(n * 32); d_o = ctx.alloc(n * 16); d_r.upload(rays)
+                    ctx.intersect_device(scene, env, d_r.ptr, d_o.ptr, n, lane=ra.LANE_AUTO)
+                    pending.append((d_r, d_o, n, off, rays))
+                    continue
+                got = ctx.intersect(scene, env, rays, lane=lane)
+                check(got, off, n, rays, lane)
+            if chained:
+                ctx.wait(ra.LANE_AUTO)
+                for d_r, d_o, n, off, rays in pending:
+                    check(d_o.download(orc.RESULT_DTYPE, n), off, n, rays, lane)
+                    d_r.free(); d_o.free()
         ts = [threading.Thread(target=work, args=(l, int(rng.integers(1 << 30)))) for l in range(opt["lanes"])]
         for t in ts: t.start()
         for t in ts: t.join()
