@@ -186,11 +186,14 @@ def main():
 
     # The traversal kernel alone on the GPU, one launch at a time (HIP events around the kernel on the stream it is launched on):
     # the launch duration `roofline.achieved` is computed from — in the timed region launches are chained, a kernel there either
-    # works through many batches or finds nothing left, so no per-launch duration exists.  Untimed, a few ms, before the warm-up.
+    # works through many batches or finds nothing left, so no per-launch duration exists.  Untimed, before the warm-up.  The
+    # duration settles only after the GPU has been busy for ~15 ms (10 launches: 0.386 ms, 100: 0.373; rocprofv3's one-lane
+    # trace of the committed profile: 0.371), so 60 launches are timed and the mean of the last 30 is reported.
     iso_ms = None
     if rank == 0:
-        ctx.intersect_device_timed(scene, env, d_rays.data_ptr(), outs[-1].data_ptr(), n, 2)
-        iso_ms = float(np.mean(ctx.intersect_device_timed(scene, env, d_rays.data_ptr(), outs[-1].data_ptr(), n, 10)))
+        iso_n = int(os.environ.get("RACC_BENCH_ISO_LAUNCHES", "60"))
+        iso_all = ctx.intersect_device_timed(scene, env, d_rays.data_ptr(), outs[-1].data_ptr(), n, iso_n)
+        iso_ms = float(np.mean(iso_all[len(iso_all) // 2:]))
 
     if args.warmup:
         run_overlapped(args.warmup)
