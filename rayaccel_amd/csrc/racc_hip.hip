@@ -598,10 +598,7 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
             lane.chainKernelEndEv = lane.chainKernelEnd;
         }
         lane.chainKernelValid = true;
-        // (a batch whose miss shading is parked gets these waits together with the shading kernel, in flushDeferredEnv: enqueued here
-        //  they would also hold up the lane's NEXT traversal kernel, and the kernels at the end of a sequence — each finds its batch
-        //  worked off and ends after microseconds — would run one after the other across the lanes instead of side by side)
-        if (chainPred >= 0 && !(v.deferEnv && env != nullptr))
+        if (chainPred >= 0)
             for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
                 Lane& other = ctx->lanes[i];
                 if (&other != &lane && other.chainKernelValid) HIP_TRY(hipStreamWaitEvent(stream, other.chainKernelEndEv, 0), "hipStreamWaitEvent(chain)");
@@ -655,13 +652,6 @@ int flushDeferredEnv(racc_hip_ctx* ctx, Lane& lane) {
     for (uint32_t i = 0; i < n; ++i) { b.b[i] = lane.deferred[i]; most = lane.deferred[i].count > most ? lane.deferred[i].count : most; }
     const racc_hip_env* env = lane.deferredEnv;
     lane.deferred.clear(); lane.deferredEnv = nullptr;
-    {   // every kernel issued before these batches may have worked on them: the latest chained kernel of every other lane must have ended
-        std::lock_guard<std::mutex> g(ctx->chainMutex);
-        for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
-            Lane& other = ctx->lanes[i];
-            if (&other != &lane && other.chainKernelValid) HIP_TRY(hipStreamWaitEvent(lane.stream, other.chainKernelEndEv, 0), "hipStreamWaitEvent(chain, parked shading)");
-        }
-    }
     uint32_t blocks = (most + 255u) / 256u;
     const uint32_t cap = uint32_t(ctx->numCUs) * 8u / (n > 4u ? 4u : n) + 1u;
     if (blocks > cap) blocks = cap;
