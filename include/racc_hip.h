@@ -182,9 +182,7 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
  * Array reuse under chained launches — the exact rule (≙ the in-place, in-order ray-stream contract, RayAccelerator.h:78-83,
  * RayAccelerator.cpp:369-410: the reference recycles a stream's arrays bounce after bounce):
  *   - a batch's ray and result arrays belong to the engine from the call until racc_hip_wait on ITS lane (or
- *     RACC_HIP_LANE_AUTO / racc_hip_synchronize) has returned; a lane's wait returns when its batch is complete, whoever traced it
- *     (the miss radiance of a lane's chained batches is filled in by ONE kernel when the lane is waited for or next used for
- *     anything else — until then their miss records hold the ray direction: another lane's wait does not make them final);
+ *     RACC_HIP_LANE_AUTO / racc_hip_synchronize) has returned; a lane's wait returns when its batch is complete, whoever traced it;
  *   - after that wait the arrays may be rewritten and re-issued AT ONCE, by any means that has completed before the next call
  *     (racc_hip_memcpy_h2d, a copy or kernel on another stream that the caller has synchronised), while the batches of the
  *     other lanes are still in flight and their kernels go on to trace the re-issued one.

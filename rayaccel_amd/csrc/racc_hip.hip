@@ -76,20 +76,6 @@ __global__ void __launch_bounds__(256) envShadeKernel(float4* results, uint32_t 
     }
 }
 
-// The same for several batches in one launch (chained launches park their miss shading until the lane is waited for: one kernel
-// for all of a lane's pending batches instead of one per batch queued behind the chain's long-lived kernels).
-struct EnvBatch { float4* results; uint32_t count; uint32_t pad; };
-constexpr uint32_t kEnvBatches = 8;
-struct EnvBatches { EnvBatch b[kEnvBatches]; };
-__global__ void __launch_bounds__(256) envShadeMultiKernel(const EnvBatches batches, const float4* env, uint32_t envW, uint32_t envH) {
-    const EnvBatch e = batches.b[blockIdx.y];
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < e.count; i += gridDim.x * 256u) {
-        const float4 rec = e.results[i];
-        if (__float_as_uint(rec.x) != kInvalidTriangle) continue;
-        e.results[i] = isnan(rec.y) ? make_float4(rec.x, 0.0f, 0.0f, 0.0f) : envSample(env, envW, envH, rec.y, rec.z, rec.w);
-    }
-}
-
 // Chained launches: writes launch `idx`'s descriptor into the ring (device memory: a drained wave reads it at L2 speed; host-mapped
 // memory cost every such wave six PCIe round trips) and links it behind its predecessor.  One thread, on the context's control stream.
 __global__ void chainPublishKernel(ChainDesc* ring, uint32_t idx, const float4* rays, float4* results, uint32_t* cursor, uint32_t count,
@@ -144,11 +130,6 @@ struct Lane {
     hipEvent_t chainKernelEnd = nullptr; // chained launches: recorded right after the lane's latest chained traversal kernel ...
     hipEvent_t chainKernelEndEv = nullptr;   // ... or, with time_kernels, that launch's timing end event (not owned)
     bool chainKernelValid = false;
-    bool lastLaunchChained = false;      // the latest launchTraverse on this lane was linked into the chain
-    // chained launches: miss shading parked until the lane is waited for (or used otherwise): result arrays whose miss records
-    // still hold the ray direction, all for `deferredEnv`
-    std::vector<EnvBatch> deferred;
-    const racc_hip_env* deferredEnv = nullptr;
 };
 constexpr uint32_t kTimeRing = 256;
 
@@ -608,7 +589,6 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
         ++ctx->chainHead;
     }
     lane.pendingEnv = v.deferEnv && env != nullptr;
-    lane.lastLaunchChained = chain;
     lane.info.grid_blocks = blocks;
     lane.info.block_threads = uint32_t(v.block);
     lane.info.lds_bytes_per_block = ldsBytes;
@@ -640,24 +620,6 @@ int launchEnvShadeOnly(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const 
     hipLaunchKernelGGL(envShadeKernel, dim3(blocks), dim3(256), 0, stream, static_cast<float4*>(dResults), count, env->pixels, env->width, env->height);
     HIP_TRY(hipGetLastError(), "launch envShadeKernel");
     return RACC_HIP_OK;
-}
-
-// Launches the parked miss shading of a lane's chained batches (one kernel for all of them) on the lane's stream: behind their
-// traversal kernels and behind the waits for every other kernel that may have worked on them (launchTraverse enqueued those).
-int flushDeferredEnv(racc_hip_ctx* ctx, Lane& lane) {
-    if (lane.deferred.empty()) return RACC_HIP_OK;
-    EnvBatches b{};
-    uint32_t most = 0;
-    const uint32_t n = uint32_t(lane.deferred.size());
-    for (uint32_t i = 0; i < n; ++i) { b.b[i] = lane.deferred[i]; most = lane.deferred[i].count > most ? lane.deferred[i].count : most; }
-    const racc_hip_env* env = lane.deferredEnv;
-    lane.deferred.clear(); lane.deferredEnv = nullptr;
-    uint32_t blocks = (most + 255u) / 256u;
-    const uint32_t cap = uint32_t(ctx->numCUs) * 8u / (n > 4u ? 4u : n) + 1u;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(envShadeMultiKernel, dim3(blocks, n), dim3(256), 0, lane.stream, b, env->pixels, env->width, env->height);
-    HIP_TRY(hipGetLastError(), "launch envShadeMultiKernel");
-    return markLaneDone(lane, lane.stream);
 }
 
 hipError_t initLane(Lane& l, bool timeKernels) {
@@ -951,12 +913,6 @@ int racc_hip_env_free(racc_hip_ctx* ctx, racc_hip_env* env) {
     if (!env) return RACC_HIP_OK;
     if (ctx) { std::lock_guard<std::mutex> g(ctx->chainMutex); if (ctx->chainLast.env == env) ctx->chainLast.valid = false; }
     if (ctx) hipSetDevice(ctx->device);
-    if (ctx)      // miss shading parked for this image (chained batches not waited for yet) runs now
-        for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
-            Lane& l = ctx->lanes[i];
-            std::lock_guard<std::mutex> guard(l.mutex);
-            if (l.deferredEnv == env) { (void)flushDeferredEnv(ctx, l); hipStreamSynchronize(l.stream); }
-        }
     if (env->pixels) hipFree(env->pixels);
     delete env;
     return RACC_HIP_OK;
@@ -1002,7 +958,6 @@ int racc_hip_intersect_async(racc_hip_ctx* ctx, const racc_hip_scene* scene, con
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     Lane& l = ctx->lanes[lane];
     std::lock_guard<std::mutex> guard(l.mutex);
-    if (int rc = flushDeferredEnv(ctx, l)) return rc;
     HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");     // staging buffers are reused per lane
     if (int rc = ensureStaging(l, count)) return rc;
     HIP_TRY(hipMemcpyAsync(l.dRays, rays, size_t(count) * 32, hipMemcpyHostToDevice, l.stream), "H2D rays");
@@ -1019,11 +974,6 @@ int racc_hip_wait(racc_hip_ctx* ctx, uint32_t lane) {
         for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
             Lane& l = ctx->lanes[i];
             std::lock_guard<std::mutex> guard(l.mutex);
-            if (int rc = flushDeferredEnv(ctx, l)) return rc;      // (all lanes first: their shading kernels run side by side)
-        }
-        for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
-            Lane& l = ctx->lanes[i];
-            std::lock_guard<std::mutex> guard(l.mutex);
             HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
             if (l.everLaunched) HIP_TRY(hipEventSynchronize(l.done), "hipEventSynchronize");
         }
@@ -1033,7 +983,6 @@ int racc_hip_wait(racc_hip_ctx* ctx, uint32_t lane) {
     {
         Lane& l = ctx->lanes[lane];
         std::lock_guard<std::mutex> guard(l.mutex);
-        if (int rc = flushDeferredEnv(ctx, l)) return rc;
         HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
         if (l.everLaunched) HIP_TRY(hipEventSynchronize(l.done), "hipEventSynchronize");
     }
@@ -1064,7 +1013,6 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     Lane& l = ctx->lanes[lane];
     std::lock_guard<std::mutex> guard(l.mutex);
-    if (int rc = flushDeferredEnv(ctx, l)) return rc;
     HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
     if (int rc = ensureStaging(l, uint32_t(total))) return rc;
     // Copies `what` (0 = rays H2D, 1 = results D2H) of the global ray range [g0, g1) on stream st, stream by stream.
@@ -1173,20 +1121,7 @@ int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, co
     Lane& l = ctx->lanes[lane];
     std::lock_guard<std::mutex> guard(l.mutex);
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : l.stream;
-    // (parked miss shading belongs to one environment and fits one launch; anything else on this lane first gets it out of the way)
-    if (!l.deferred.empty() && (stream != nullptr || l.deferredEnv != env || l.deferred.size() >= kEnvBatches))
-        if (int rc = flushDeferredEnv(ctx, l)) return rc;
     if (int rc = launchTraverse(ctx, l, st, scene, env, d_rays, d_results, count, /*mayChain=*/stream == nullptr)) return rc;
-    if (l.lastLaunchChained && l.pendingEnv && env) {
-        // Chained: the batch is complete only when every kernel issued before it has ended, i.e. at the end of the sequence — a
-        // shading kernel per batch would queue up there, three streams wide, behind one another's cross-stream waits (20 batches:
-        // 0.37 ms of tail).  Park it: racc_hip_wait (or the next other use of the lane) shades all of the lane's batches at once.
-        l.pendingEnv = false;
-        l.deferred.push_back(EnvBatch{static_cast<float4*>(d_results), count, 0u});
-        l.deferredEnv = env;
-        return markLaneDone(l, st);
-    }
-    if (!l.deferred.empty()) if (int rc = flushDeferredEnv(ctx, l)) return rc;      // (this launch was not chained after all)
     return launchEnvShade(ctx, l, st, env, d_results, count);
 }
 
@@ -1199,7 +1134,6 @@ int racc_hip_intersect_device_timed(racc_hip_ctx* ctx, const racc_hip_scene* sce
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     Lane& l = ctx->lanes[lane];
     std::lock_guard<std::mutex> guard(l.mutex);
-    if (int rc = flushDeferredEnv(ctx, l)) return rc;
     while (l.events.size() < size_t(iters) * 2) {
         hipEvent_t ev;
         HIP_TRY(hipEventCreate(&ev), "hipEventCreate");
@@ -1602,11 +1536,6 @@ int racc_hip_group_wait(racc_hip_group* g) {
 int racc_hip_synchronize(racc_hip_ctx* ctx) {
     if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
-    for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
-        Lane& l = ctx->lanes[i];
-        std::lock_guard<std::mutex> guard(l.mutex);
-        if (int rc = flushDeferredEnv(ctx, l)) return rc;
-    }
     HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
     return checkWatchdog(ctx);
 }
