@@ -537,8 +537,12 @@ int launchTraverse(racc_hip_ctx* ctx, Lane& lane, hipStream_t stream, const racc
     a.spillStride = gridThreads;
     a.chunk = optOr(ctx->opts.chunk, 64u * uint32_t(v.slots));
     if (a.chunk > 65536u) a.chunk = 65536u;      // grid waves x chunk (the statically assigned first chunks) must stay far below 2^32
-    a.refillMin = optOr(ctx->opts.refill_min, 20u);      // tools/gpu_policy_sweep.py: 12-20 idle lanes beat 32 by 2 % (4M-ray launch) to 3 % (1M-ray launches back to back); 44: -15 %
-    a.leafMin = optOr(ctx->opts.leaf_min, v.wide ? 6u : 12u);      // (the wide kernels' optimum, tools/gpu_policy_sweep.py: 4M 1.115 vs 1.15 ms, back to back 0.265 vs 0.278)
+    // tools/gpu_policy_sweep.py.  Round 2: 12-20 idle lanes beat 32 by 2 % (4M-ray launch) to 3 % (1M-ray launches back to back); 44: -15 %.
+    // Round 3, after the refill lost its scratch round trips: binary kernel refill at 12 / leaf step at 10 waiting lanes
+    // 0.2255-0.2261 ms back to back, 1.062-1.064 per 4M rays against 0.2309-0.2319 / 1.070-1.079 with 20 / 12; the wide kernels
+    // stay at 20 / 6 (12 / 6: 0.2185 vs 0.2176; 20 / 10: 0.2153).
+    a.refillMin = optOr(ctx->opts.refill_min, v.wide ? 20u : 12u);
+    a.leafMin = optOr(ctx->opts.leaf_min, v.wide ? 6u : 10u);
     a.maxIters = ctx->maxIters;
     a.trips = ctx->devTrips;
     a.tailActive = ctx->opts.tail_active ? (ctx->opts.tail_active > 64u ? 0u : ctx->opts.tail_active) : 32u;   // >64 disables

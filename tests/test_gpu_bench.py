@@ -27,8 +27,12 @@ def test_single_gpu_line():
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["unit"] == "Mrays/s"
     assert d["value"] > 0 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
-    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0 and d["roofline"]["kernel_ms_avg"] > 0
-    assert d["roofline"]["algorithmic"]["bytes_per_launch"] > 0 and d["one_launch_at_a_time"]["mrays_per_s"] > 0 if "one_launch_at_a_time" in d else True
+    r = d["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r)        # the measurement contract's keys
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["kernel_ms_avg"] > 0
+    # achieved = algorithmic bytes (oracle counters, live) / the kernel's isolated launch duration (HIP events); frac = achieved / peak
+    assert r["algorithmic_bytes_per_launch"] > 0 and abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e9) < 0.01 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["timed_region"]["ms_per_step"] == d["ms_per_step"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
 
 
