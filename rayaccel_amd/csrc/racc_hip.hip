@@ -342,6 +342,9 @@ int quantiseWide(const std::vector<WideNode>& in, std::vector<WideNodeQ>& out) {
         std::memcpy(r.ref, w.ref, sizeof(r.ref));
         bool used[4];
         for (int i = 0; i < 4; ++i) used[i] = !std::isinf(w.plane[0][i]);
+        for (int i = 0; i < 4; ++i)
+            for (int pl = 0; pl < 6; ++pl)
+                if (used[i] && !std::isfinite(w.plane[pl][i])) return fail(RACC_HIP_ERR_INVALID, "scene blob: a child box is not finite (the compressed 4-wide format cannot hold it)");
         float scl[3];
         for (int ax = 0; ax < 3; ++ax) {
             float lo = std::numeric_limits<float>::infinity(), hi = -lo;
