@@ -189,11 +189,10 @@ def main():
     # works through many batches or finds nothing left, so no per-launch duration exists.  Untimed, before the warm-up.  The
     # duration settles only after the GPU has been busy for ~15 ms (10 launches: 0.386 ms, 100: 0.373; rocprofv3's one-lane
     # trace of the committed profile: 0.371), so 60 launches are timed and the mean of the last 30 is reported.
-    iso_ms = None
-    if rank == 0:
-        iso_n = int(os.environ.get("RACC_BENCH_ISO_LAUNCHES", "60"))
-        iso_all = ctx.intersect_device_timed(scene, env, d_rays.data_ptr(), outs[-1].data_ptr(), n, iso_n)
-        iso_ms = float(np.mean(iso_all[len(iso_all) // 2:]))
+    # (every rank does it: at N > 1 all GPUs enter the timed region in the same state, and the line reports rank 0's)
+    iso_n = int(os.environ.get("RACC_BENCH_ISO_LAUNCHES", "60"))
+    iso_all = ctx.intersect_device_timed(scene, env, d_rays.data_ptr(), outs[-1].data_ptr(), n, iso_n)
+    iso_ms = float(np.mean(iso_all[len(iso_all) // 2:]))
 
     if args.warmup:
         run_overlapped(args.warmup)
