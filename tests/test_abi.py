@@ -77,3 +77,21 @@ def test_shipped_build_has_the_v8_kernels_only():
     experimental = b"experimental" in lib.racc_hip_version()
     assert bool(lib.racc_hip_variant_available(22)) == experimental
     assert ra.engine.Options.__dict__ is not None and __import__("ctypes").sizeof(ra.engine.Options) == 68      # the options block is ABI: 17 words (struct_size tells older callers apart)
+
+
+def test_traversal_kernels_use_no_scratch():
+    """Round 3's finding: with the ray constants as plain inputs of the assembly block the register allocator spilled
+    a copy of them around it — scratch stores per lane per refill that made 7.7 x the compulsory write traffic.  No shipped traversal
+    kernel may need scratch again, and the default ones must keep five waves per SIMD."""
+    import re
+    import subprocess
+    from rayaccel_amd import engine
+    out = subprocess.run(["make", "-s", "-C", engine.CSRC, "resources"], capture_output=True, text=True, timeout=600)
+    text = out.stdout + out.stderr
+    rows = re.findall(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)", text, re.S)
+    kernels = {name: (int(scratch), int(occ)) for name, scratch, occ in rows if "traverseKernel" in name}
+    assert len(kernels) >= 15, text[-2000:]
+    assert all(s == 0 for s, _ in kernels.values()), {k: v for k, v in kernels.items() if v[0]}
+    for name, (_, occ) in kernels.items():
+        if "traverseKernelV8ILi256ELi13" in name or "traverseKernelV10ILi256ELi15ELb0ELb1" in name:
+            assert occ >= 5, (name, occ)
