@@ -196,7 +196,12 @@ int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, c
  * issued before it have ended (their end-of-kernel release writes the L2s back), which is what the lane's wait waits for.
  * tests/test_gpu_reuse.py recycles three ray and three result buffers through 2,000 chained batches of 64 ... 1M rays, rewritten
  * by host copies and by a copy kernel on another stream, on a scene that thrashes the L2s and on one that leaves them idle:
- * every batch bit-exact. */
+ * every batch bit-exact.
+ * What this rests on: the dispatch-packet acquire is behaviour of the HIP runtime and the command processor, not of this library —
+ * established on ROCm 7.2 (HIP 7.2.26015), gfx950 in SPX partition mode, and checked there by the test above, not derived from a
+ * specification.  On any other runtime or partition mode the GUARANTEED rule is the stricter one: re-issue an array only after
+ * racc_hip_synchronize (no kernel of the chain is alive then), or create the context with chain_launches = 2 (every launch stands
+ * alone; a kernel never outlives the boundary that publishes its inputs). */
 int racc_hip_intersect_device(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
                               const void* d_rays, void* d_results, uint32_t count,
                               uint32_t lane, void* stream);

@@ -286,10 +286,12 @@ class Context:
         self.lanes, self.auto_lanes = int(n.value), int(rot.value)      # lanes the context has / lanes LANE_AUTO rotates over
         self.device = device
 
+    _owned = True      # False: a group member's context, borrowed (Group.member): the group destroys it
+
     def destroy(self):
-        if self._h:
+        if self._h and self._owned:
             load_library().racc_hip_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __enter__(self):
         return self
@@ -397,7 +399,7 @@ class Group:
         arr = (C.c_int * len(devices))(*devices)
         h = C.c_void_p()
         _check(lib.racc_hip_group_create(arr, len(devices), None, C.byref(h)))
-        self._h, self.size = h, lib.racc_hip_group_size(h)
+        self._h, self.size, self.devices = h, lib.racc_hip_group_size(h), list(devices)
         self._scene = self._env = None
 
     def upload(self, nodes, pairs, remap, env_rgba=None):
@@ -420,9 +422,15 @@ class Group:
 
     def member(self, i):
         """The i-th member's engine context as a borrowed Context (device memory helpers, lanes)."""
+        lib = load_library()
         c = Context.__new__(Context)
-        c._h = C.c_void_p(load_library().racc_hip_group_ctx(self._h, i))
-        c.device, c.lanes, c.auto_lanes = None, None, None
+        c._h = C.c_void_p(lib.racc_hip_group_ctx(self._h, i))
+        if not c._h:
+            raise RaccError(-1, "group has no member %d" % i)
+        c._owned = False          # destroy() / `with` on it only drops the reference: racc_hip_group_destroy frees the member
+        n, rot = C.c_uint32(), C.c_uint32()
+        _check(lib.racc_hip_lane_count(c._h, C.byref(n), C.byref(rot)))
+        c.lanes, c.auto_lanes, c.device = int(n.value), int(rot.value), self.devices[i]
         return c
 
     def intersect_device(self, d_rays, d_results, counts):

@@ -28,6 +28,18 @@ def test_header_symbols_are_exported_and_bound():
     assert ra.load_library().racc_hip_version().startswith(b"racc-hip")
 
 
+def test_nothing_but_the_c_abi_is_exported():
+    """Round-3 verdict: `rccl`, `failRccl`, `groupCollect` left libracc_hip.so unprefixed (helpers inside `extern "C"`).  The link
+    step now carries an export list (rayaccel_amd/csrc/racc_hip.map): every dynamic symbol the library defines is a racc_hip_* /
+    racc_host_* entry — no C++ template instantiations, no helper a host program's own `rccl` could collide with."""
+    out = os.popen("nm -D --defined-only %s" % engine.LIB_PATH).read().split("\n")
+    names = [l.split()[-1] for l in out if l.strip()]
+    assert len(names) >= 50
+    stray = [n for n in names if not re.match(r"racc_(hip|host)_[a-z0-9_]+$", n)]
+    assert not stray, stray
+    assert set(_declared()) <= set(names)
+
+
 def test_struct_layouts_match_header():
     assert C.sizeof(engine.Options) == 17 * 4
     assert C.sizeof(engine.SceneInfo) == 32 and C.sizeof(engine.LaunchInfo) == 20

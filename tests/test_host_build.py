@@ -1,9 +1,13 @@
 """CPU tests of the product's host-side scene build (rayaccel_amd/csrc/scene_build.cpp) against the
 oracle's restatement of Bvh2.cpp / Scene.cpp: index and byte work, so BIT-EXACT."""
+import os
+
 import numpy as np
 import pytest
 
 import rayaccel_amd as ra
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from oracle import oracle as orc
 from rayaccel_amd import synth
 
@@ -158,3 +162,14 @@ def test_material_sampling_matches_the_reference_restatement():
         np.testing.assert_allclose(wi[refl], wi_a[refl], rtol=0, atol=3e-6)
         cosang = np.clip((wi[~refl].astype(np.float64) * wi_a[~refl]).sum(1), -1, 1)
         assert np.degrees(np.arccos(cosang)).max() < 4.0                  # the reference's parabola sine/cosine: <= 0.056 off before normalisation
+
+
+def test_group_workers_under_thread_sanitizer():
+    """The device group's persistent per-GPU worker threads (rayaccel_amd/csrc/racc_group_worker.h) in a GPU-free -fsanitize=thread
+    harness (`make tsan`, tests/cpp/group_worker_tsan.cpp): four caller threads, three workers, post / drain / collect as
+    racc_hip_group_intersect_device + racc_hip_group_wait do.  No race, no lost job, failures collected once."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "group_worker_tsan")
+    assert os.path.exists(exe), "make -C rayaccel_amd/csrc tsan"
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66"))
+    assert p.returncode == 0 and "ThreadSanitizer" not in p.stderr, p.stdout + p.stderr[-3000:]
