@@ -13,7 +13,7 @@ batch go on with the next step's (include/racc_hip.h, chain_launches), so no ste
 leaves the machine empty; every step has its own result array; the timed region ends when
 every step's results are in HBM.  Output: ONE JSON line on rank 0.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]         # N > 1 as a plain command: re-executes itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
     ... bench.py --mode strong      # BASELINE configs[3] as written: ONE 8M-ray batch cut into N contiguous shards,
                                     # second figure with the RCCL all-gather of the hit records inside the timed region
@@ -105,13 +105,19 @@ def main():
     ap.add_argument("--engine-opts", default="", help="JSON dict of racc_hip_options overrides (kernel A/B and profiling runs only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Started as a plain command (`python bench.py --gpus N ...`): become the launcher — one rank per GPU under
+        # torch.distributed.run on a free local port, same arguments; rank 0's line is the only thing on stdout.
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-        args.gpus = world
+    args.gpus = world
 
     import numpy as np
     import torch                      # first: the engine then shares torch's HIP runtime in this process
@@ -210,10 +216,15 @@ def main():
     for k in range(1, min(args.steps, len(outs))):      # every step traced the same batch: every result array must hold the same bits
         if not torch.equal(outs[k].view(torch.int32), outs[0].view(torch.int32)):
             sys.exit("bench: step %d of the timed region produced other results than step 0" % k)
+    per_rank, comm_ranks = [elapsed], 1
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        cdev = "cuda" if backend == "nccl" else "cpu"
+        mine = torch.tensor([elapsed, 1.0], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                                   # RCCL over xGMI when backend == nccl
+        per_rank = [float(t[0].item()) for t in every]
+        comm_ranks = int(round(sum(float(t[1].item()) for t in every)))      # ranks that took part in the collective
+        elapsed = max(per_rank)
 
     value = total_rays * args.steps / elapsed / 1e6
     launch = ctx.launch_info()
@@ -522,6 +533,9 @@ def main():
                        "grid_blocks": launch["grid_blocks"], "waves_per_simd": launch["waves_per_simd"], "lanes": lanes,
                        "lanes_in_rotation": ctx.auto_lanes, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
+            # what the N > 1 figure is made of: every rank's own rate over ITS K steps, and how many ranks the communicator had
+            "per_rank_mrays_per_s": [round(n * args.steps / t / 1e6, 1) for t in per_rank] if args.mode == "weak" else [round((total_rays / world) * args.steps / t / 1e6, 1) for t in per_rank],
+            "collective_backend": (backend if world > 1 else None), "rccl_ranks": (comm_ranks if (world > 1 and backend == "nccl") else None), "comm_ranks": comm_ranks,
         }
         line.update(extras)
         print(json.dumps(line), flush=True)

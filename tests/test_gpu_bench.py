@@ -53,3 +53,17 @@ def test_strong_scaling_mode_two_ranks_rehearsal():
                "--master-port", "29547", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--grid", "128", "--no-extras", "--mode", "strong"], env)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["rays_per_gpu"] == 4 << 20 and "contiguous shards" in d["config"]["workload"]
+
+
+def test_plain_command_with_two_gpus_spawns_its_own_ranks():
+    """Round-3 verdict: `python bench.py --gpus N` started as a plain command exited with an error; if the driver's scaling run
+    mirrors its N=1 command, every N > 1 point would have failed before it started.  Now the plain form re-executes itself under
+    torch.distributed.run (rehearsed with gloo, both ranks on GPU 0); the line says how many ranks the collective had and every
+    rank's own rate."""
+    env = dict(os.environ, RACC_BENCH_BACKEND="gloo", RACC_BENCH_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    d = _line([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--grid", "128", "--no-extras"], env)
+    assert d["n_gpus"] == 2 and d["comm_ranks"] == 2 and d["collective_backend"] == "gloo" and d["rccl_ranks"] is None
+    assert len(d["per_rank_mrays_per_s"]) == 2 and all(v > 0 for v in d["per_rank_mrays_per_s"])
+    assert d["value"] <= sum(d["per_rank_mrays_per_s"]) * 1.001          # whole-job rate = all rays / the slowest rank's time

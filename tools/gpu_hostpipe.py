@@ -1,0 +1,48 @@
+"""Host RayStream batches issued back to back: racc_hip_intersect_async on rotating lanes (copies of batch k+1 beside the kernel of
+batch k beside the copy-out of batch k-1), page-locked arrays.  Prints Grays/s and the H2D / D2H rates separately.
+   python tools/gpu_hostpipe.py [batches] [rays per batch]"""
+import ctypes as C, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import rayaccel_amd as ra
+from rayaccel_amd import synth
+from oracle import oracle as orc
+
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20
+sc = synth.battlefield_synth()
+host = ra.HostScene(sc["vertices"], sc["indices"])
+prim, _ = synth.primary_rays(sc["camera"], 1024, 1024)
+ref0 = orc.traverse(host.blobs(), prim, threads=16)
+batches = [np.ascontiguousarray(np.concatenate([synth.diffuse_bounce_rays(sc, prim, ref0, 1 << 20, first_sample=4 * k + s) for s in range((n + (1 << 20) - 1) >> 20)])[:n]) for k in range(nb)]
+refs = [orc.traverse(host.blobs(), b, env=sc["env"], threads=16) for b in batches]
+outs = [np.zeros(n, ra.RESULT_DTYPE) for _ in range(nb)]
+lib = ra.load_library()
+for lanes in (1, 2, 3, 4, 6):
+    with ra.Context(device=0, lanes=lanes) as ctx:
+        scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
+        env = ctx.create_environment(sc["env"])
+        for a in batches + outs:
+            assert lib.racc_hip_register_host(ctx._h, a.ctypes.data, a.nbytes) == 0
+        def run():
+            for k in range(nb):
+                rc = lib.racc_hip_intersect_async(ctx._h, scene._h, env._h, batches[k].ctypes.data_as(C.c_void_p), outs[k].ctypes.data_as(C.c_void_p), n, k % lanes)
+                assert rc == 0, lib.racc_hip_last_error()
+            ctx.wait(ra.LANE_AUTO)
+        run()
+        best = 1e9
+        for _ in range(3):
+            for o in outs: o[:] = 0
+            t = time.perf_counter(); run(); best = min(best, time.perf_counter() - t)
+        ok = all(np.array_equal(o["triangle"], r["triangle"]) and np.array_equal(o["t"][r["triangle"] != 0xFFFFFFFF].view(np.uint32), r["t"][r["triangle"] != 0xFFFFFFFF].view(np.uint32)) for o, r in zip(outs, refs))
+        print(json.dumps(dict(lanes=lanes, batches=nb, rays=n, grays=round(nb * n / best / 1e9, 3), h2d_gbs=round(nb * n * 32 / best / 1e9, 1), d2h_gbs=round(nb * n * 16 / best / 1e9, 1), bit_exact=bool(ok))), flush=True)
+        # the blocking, sliced entry for comparison (one batch at a time)
+        if lanes == 3:
+            ctx.intersect(scene, env, batches[0], outs[0])
+            t = time.perf_counter()
+            for k in range(nb): ctx.intersect(scene, env, batches[k], outs[k])
+            dt = time.perf_counter() - t
+            print(json.dumps(dict(blocking_sliced=True, grays=round(nb * n / dt / 1e9, 3))), flush=True)
+        for a in batches + outs:
+            lib.racc_hip_unregister_host(ctx._h, a.ctypes.data)
+        scene.destroy(); env.destroy()

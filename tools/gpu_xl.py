@@ -19,9 +19,12 @@ t2 = time.time()
 with ra.Context(device=0, kernel_variant=variant, lanes=1, chain_launches=2) as ctx:
     scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
     env = ctx.create_environment(sc["env"])
-    prim, _ = synth.primary_rays(sc["camera"], 1024, 1024)
+    cam = sc["camera"]
+    if kind == "aerial":       # a view from above that covers the whole terrain: the first bounce then starts everywhere in the scene
+        cam = dict(origin=np.array([0.0, 420.0, 0.0], np.float32), target=np.array([0.0, 0.0, 0.0], np.float32), up=np.array([0.0, 0.0, 1.0], np.float32), fov=26.0)
+    prim, _ = synth.primary_rays(cam, 1024, 1024)
     hits = ctx.intersect(scene, env, prim)
-    rays = synth.diffuse_bounce_rays(sc, prim, hits, 1 << 20) if kind == "diffuse" else synth.random_rays(1 << 20, 7)
+    rays = synth.random_rays(1 << 20, 7) if kind == "random" else synth.diffuse_bounce_rays(sc, prim, hits, 1 << 20)
     n = len(rays)
     d_r = ctx.alloc(n * 32); d_o = ctx.alloc(n * 16); d_r.upload(rays)
     ms = ctx.intersect_device_timed(scene, env, d_r.ptr, d_o.ptr, n, iters)

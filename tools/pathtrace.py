@@ -6,6 +6,7 @@ no exchange during rendering) and the partial frame buffers are summed with ONE 
 this workload that really exchanges data).  Prints one JSON line on rank 0 and optionally writes a PFM image.
 
     python tools/pathtrace.py --width 1920 --height 1080 --spp 64 [--out frame.pfm]
+    python tools/pathtrace.py --gpus 8 --spp 64            # re-executes itself under torch.distributed.run
     python -m torch.distributed.run --nproc-per-node 8 ... tools/pathtrace.py --spp 64
 """
 import argparse, json, os, sys, tempfile, time
@@ -26,7 +27,15 @@ def main():
     ap.add_argument("--shading", default="gpu", choices=("gpu", "cpu"), help="gpu: device-resident consumer (pt_device.hip); "
                     "cpu: spawn/shade callbacks on host threads as in the reference (pathtracer.cpp).  Same image either way.")
     ap.add_argument("--batch", type=int, default=0, help="samples per wavefront batch (gpu shading); 0 = 8")
+    ap.add_argument("--gpus", type=int, default=0, help="started as a plain command with --gpus N > 1: re-executes itself under torch.distributed.run, one rank per GPU")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
     import numpy as np
     import torch
