@@ -151,7 +151,13 @@ int racc_hip_unregister_host(racc_hip_ctx* ctx, void* ptr);
  * run concurrently from different threads.  env may be NULL (miss rgb = 0).  Blocking. */
 int racc_hip_intersect(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
                        const void* rays, void* results, uint32_t count, uint32_t lane);
-/* Same, split into enqueue and wait (≙ clEnqueueNDRangeKernel / clFinish). */
+/* Same, split into enqueue and wait (≙ clEnqueueNDRangeKernel / clFinish).  The enqueue returns as soon as the batch's three stages
+ * — rays in over PCIe, traversal, results out over PCIe — are queued; it blocks only while the SAME lane's previous host batch is
+ * still in flight (a lane has one pair of staging arrays).  With page-locked arrays (racc_hip_register_*) the stages of batches
+ * issued on different lanes overlap: all copies into the GPU go through one stream, back to back, all copies out through another,
+ * the kernels run on the lanes' streams in between — a caller that rotates 3-4 lanes keeps the link busy in both directions
+ * (≙ the reference's gpuSubmissionThreads queues, RayAccelerator.cpp:711-717; 1M-ray batches back to back: DESIGN.md §6).
+ * The host arrays belong to the engine until racc_hip_wait on the lane (or RACC_HIP_LANE_AUTO: every lane) has returned. */
 int racc_hip_intersect_async(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
                              const void* rays, void* results, uint32_t count, uint32_t lane);
 int racc_hip_wait(racc_hip_ctx* ctx, uint32_t lane);
@@ -165,6 +171,11 @@ int racc_hip_wait(racc_hip_ctx* ctx, uint32_t lane);
 int racc_hip_intersect_streams(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
                                uint32_t n_streams, const void* const* rays, void* const* results,
                                const uint32_t* counts, uint32_t lane);
+/* The same without the wait (≙ racc_hip_intersect_async for a set of streams): the pointer arrays are read during the call, the
+ * ray/result arrays belong to the engine until racc_hip_wait(ctx, lane). */
+int racc_hip_intersect_streams_async(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
+                                     uint32_t n_streams, const void* const* rays, void* const* results,
+                                     const uint32_t* counts, uint32_t lane);
 
 /* Device-resident variant: d_rays/d_results are device pointers (e.g. torch tensors' data_ptr()).
  * `stream` is a hipStream_t passed as void* (NULL => the lane's own stream).  Asynchronous.
@@ -303,6 +314,16 @@ int racc_host_scene_blobs(const racc_host_scene* scene,
 int racc_host_scene_bvh2(const racc_host_scene* scene,
                          const void** nodes48, uint32_t* node_count,
                          const uint32_t** triangles, uint32_t* triangle_count);
+
+/* The device layout racc_hip_scene_upload gives the node blob (for tools and tests; needs no GPU).  Device record, 64 B: words 0-1 =
+ * the two child references (re-numbered), words 2-3 unused, then the child boxes as six (min, max) plane pairs: Lx Ly Lz Rx Ry Rz.
+ * order 1 (the default of racc_hip_scene_upload): every 128-byte line holds a node and, behind it, its inner child with the larger
+ * box — a ray that goes on into that child finds its record in the line it has just fetched — lines in depth-first order; nodes whose
+ * children are both leaves share lines pairwise; all-zero padding records (no reference points at them) fill the rest, so *count may
+ * exceed node_count.  order 0: the 4096 nodes with the largest boxes first, the rest in the blob's order (round 1-3 layout).
+ * out64 may be NULL (then only *count is returned); capacity in records. */
+int racc_host_scene_device_nodes(const void* nodes64, uint32_t node_count, uint32_t pair_count, uint32_t remap_count, int order,
+                                 void* out64, uint32_t capacity, uint32_t* count);
 
 #ifdef __cplusplus
 }

@@ -110,7 +110,10 @@ struct Lane {
     void* dResults = nullptr;
     uint32_t capacity = 0;
     std::vector<hipEvent_t> events;
-    hipStream_t copyIn = nullptr, copyOut = nullptr;   // host-buffer path: copies of slice k+1 / k-1 run beside the kernel of slice k
+    // host-buffer path (racc_hostpath.inc): the lane's staging arrays serve one host batch at a time; `hostOut` (on the context's copy-out
+    // stream, or on the lane's stream for pageable arrays) marks the batch complete
+    hipEvent_t hostOut = nullptr;
+    std::atomic<bool> hostPending{false};
     std::vector<hipEvent_t> pipeEvents;
     racc_hip_launch_info info{};
     bool pendingEnv = false;             // last traversal launch parked miss directions: envShade must follow
@@ -156,12 +159,15 @@ struct racc_hip_ctx {
     std::mutex chainMutex;
     struct { const racc_hip_scene* scene = nullptr; const racc_hip_env* env = nullptr; const void* kernel = nullptr; uint32_t idx = 0; Lane* lane = nullptr; bool valid = false; } chainLast;
     bool chainEnabled = true;            // RACC_CHAIN=0 switches it off
+    hipStream_t pipeIn = nullptr, pipeOut = nullptr;      // host-buffer path: ONE copy-in and ONE copy-out stream per context (racc_hostpath.inc), created on first use
+    std::mutex pipeMutex;
     bool raysBypassL1 = true;            // chained kernels load rays with system-scope loads (RACC_RAY_SCOPE=0: plain loads, A/B only)
     uint32_t maxIters = 1u << 24;        // RACC_MAX_ITERS overrides (tests)
 };
 
 struct racc_hip_scene {
     float4* nodes = nullptr;
+    uint32_t deviceNodes = 0;       // records in `nodes`: the scene's inner nodes plus the padding records of the line-paired order (reorderNodes)
     float4* nodesWide = nullptr;    // the same tree collapsed into 4-wide 128 B records (collapseWide)
     float4* nodesWideQ = nullptr;   // ... and those compressed to 64 B: child boxes quantised to 8 bits per plane on the box around them (quantiseWide)
     uint32_t wideCount = 0;
@@ -305,6 +311,8 @@ int racc_hip_destroy(racc_hip_ctx* ctx) {
     if (ctx->chainStream) hipStreamDestroy(ctx->chainStream);
     if (ctx->chainCursors) hipFree(ctx->chainCursors);
     for (Lane& l : ctx->lanes) freeLane(l);
+    if (ctx->pipeIn) hipStreamDestroy(ctx->pipeIn);
+    if (ctx->pipeOut) hipStreamDestroy(ctx->pipeOut);
     delete ctx;
     return RACC_HIP_OK;
 }
@@ -320,25 +328,31 @@ int racc_hip_scene_upload(racc_hip_ctx* ctx, const void* nodes64, uint32_t node_
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     racc_hip_scene* s = new (std::nothrow) racc_hip_scene();
     if (!s) return fail(RACC_HIP_ERR_NOMEM, "out of host memory");
-    const size_t nb = size_t(node_count) * 64, pb = size_t(pair_count) * 48, rb = size_t(remap_count) * 4;
+    const size_t pb = size_t(pair_count) * 48, rb = size_t(remap_count) * 4;
+    const Variant& own = pickVariant(ctx, info.inner_height);
+    int order = own.cacheNodes > 0 ? 0 : 1;      // (kernels with an LDS node cache — experimental builds — want the largest boxes first)
+    if (const char* o = std::getenv("RACC_NODE_ORDER")) order = std::atoi(o) == 0 ? 0 : 1;
+    std::vector<GpuNodeHost> ordered;
+    reorderNodes(static_cast<const GpuNodeHost*>(nodes64), node_count, ordered, order);
+    if (ordered.size() > (size_t(1) << 26)) { delete s; return fail(RACC_HIP_ERR_LIMIT, "more than 2^26 device node records"); }
+    s->deviceNodes = uint32_t(ordered.size());
+    const size_t nb = ordered.size() * 64;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->nodes), nb);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->pairs), pb);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->remap), rb ? rb : 4);
-    std::vector<GpuNodeHost> ordered;
-    reorderNodes(static_cast<const GpuNodeHost*>(nodes64), node_count, ordered);
     if (e == hipSuccess) e = hipMemcpy(s->nodes, ordered.data(), nb, hipMemcpyHostToDevice);
     if (e == hipSuccess && ctx->opts.kernel_variant == uint32_t(kSoaVariant)) {
-        std::vector<float> planes(size_t(node_count) * 16);
+        const uint32_t dn = s->deviceNodes;
+        std::vector<float> planes(size_t(dn) * 16);
         const float* rec = reinterpret_cast<const float*>(ordered.data());
-        for (uint32_t i = 0; i < node_count; ++i)
+        for (uint32_t i = 0; i < dn; ++i)
             for (uint32_t p = 0; p < 4; ++p)
-                std::memcpy(&planes[(size_t(p) * node_count + i) * 4], rec + size_t(i) * 16 + p * 4, 16);
+                std::memcpy(&planes[(size_t(p) * dn + i) * 4], rec + size_t(i) * 16 + p * 4, 16);
         e = hipMalloc(reinterpret_cast<void**>(&s->nodesSoa), nb);
         if (e == hipSuccess) e = hipMemcpy(s->nodesSoa, planes.data(), nb, hipMemcpyHostToDevice);
     }
     size_t wb = 0;
     // the 4-wide copies of the tree only for contexts that can select a wide kernel (each costs device memory like the nodes)
-    const Variant& own = pickVariant(ctx, info.inner_height);
     if (e == hipSuccess && (own.wide || ctx->opts.wide_below != 0u)) {
         std::vector<WideNode> wide;
         collapseWide(static_cast<const GpuNodeHost*>(nodes64), node_count, wide, s->wideStack);
@@ -369,6 +383,22 @@ int racc_hip_scene_upload(racc_hip_ctx* ctx, const void* nodes64, uint32_t node_
     }
     s->info = info;
     *out = s;
+    return RACC_HIP_OK;
+}
+
+int racc_host_scene_device_nodes(const void* nodes64, uint32_t node_count, uint32_t pair_count, uint32_t remap_count, int order,
+                                 void* out64, uint32_t capacity, uint32_t* count) {
+    if (!nodes64 || !count) return fail(RACC_HIP_ERR_INVALID, "device_nodes: NULL argument");
+    *count = 0;
+    racc_hip_scene_info info{};
+    if (int rc = validateScene(static_cast<const GpuNodeHost*>(nodes64), node_count, pair_count, remap_count, info)) return rc;
+    std::vector<GpuNodeHost> ordered;
+    reorderNodes(static_cast<const GpuNodeHost*>(nodes64), node_count, ordered, order == 0 ? 0 : 1);
+    *count = uint32_t(ordered.size());
+    if (out64) {
+        if (capacity < ordered.size()) return fail(RACC_HIP_ERR_INVALID, "device_nodes: capacity too small");
+        std::memcpy(out64, ordered.data(), ordered.size() * sizeof(GpuNodeHost));
+    }
     return RACC_HIP_OK;
 }
 

@@ -79,6 +79,7 @@ ABI = {
     "racc_hip_intersect_async": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32]),
     "racc_hip_wait": (_i, [_vp, _u32]),
     "racc_hip_intersect_streams": (_i, [_vp, _vp, _vp, _u32, _P(_vp), _P(_vp), _P(_u32), _u32]),
+    "racc_hip_intersect_streams_async": (_i, [_vp, _vp, _vp, _u32, _P(_vp), _P(_vp), _P(_u32), _u32]),
     "racc_hip_intersect_device": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "racc_hip_intersect_device_timed": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _P(C.c_float)]),
     "racc_hip_get_launch_info": (_i, [_vp, _u32, _P(LaunchInfo)]),
@@ -112,6 +113,7 @@ ABI = {
     "racc_host_scene_free": (_i, [_vp]),
     "racc_host_scene_blobs": (_i, [_vp, _P(_vp), _P(_u32), _P(_vp), _P(_u32), _P(_u32), _P(_vp), _P(_u32)]),
     "racc_host_scene_bvh2": (_i, [_vp, _P(_vp), _P(_u32), _P(_vp), _P(_u32)]),
+    "racc_host_scene_device_nodes": (_i, [_vp, _u32, _u32, _u32, _i, _vp, _u32, _P(_u32)]),
 }
 
 _lib = None
@@ -208,6 +210,17 @@ class HostScene:
 
     def blobs(self):
         return dict(nodes=self.nodes, pairs=self.pairs, remap=self.remap, pair_count=self.pair_count)
+
+    def device_nodes(self, order=1):
+        """The 64 B device records racc_hip_scene_upload lays the node blob out as (racc_host_scene_device_nodes; no GPU needed):
+        [N', 16] uint32 words — child refs in words 0-1, the boxes as (min, max) plane pairs in words 4-15."""
+        lib = load_library()
+        n = C.c_uint32(0)
+        args = (_ptr(self.nodes), len(self.nodes), len(self.pairs), len(self.remap), order)
+        _check(lib.racc_host_scene_device_nodes(*args, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 16), np.uint32)
+        _check(lib.racc_host_scene_device_nodes(*args, _ptr(out), n.value, C.byref(n)))
+        return out
 
 
 class Scene:
@@ -331,6 +344,19 @@ class Context:
             results = np.zeros(len(rays), RESULT_DTYPE)
         _check(load_library().racc_hip_intersect(self._h, scene._h, env._h if env else None, _ptr(rays), _ptr(results), len(rays), lane))
         return results
+
+    def intersect_async(self, scene, env, rays, results, lane=0):
+        """Enqueue only (racc_hip_intersect_async): `rays` / `results` must stay alive and untouched until wait(lane)."""
+        assert rays.dtype.itemsize == 32 and results.dtype.itemsize == 16 and rays.flags.c_contiguous and results.flags.c_contiguous
+        _check(load_library().racc_hip_intersect_async(self._h, scene._h, env._h if env else None, _ptr(rays), _ptr(results), len(rays), lane))
+
+    def register_host(self, array):
+        """Page-locks a numpy array (racc_hip_register_host); returns a token for unregister_host."""
+        _check(load_library().racc_hip_register_host(self._h, array.ctypes.data, array.nbytes))
+        return array.ctypes.data
+
+    def unregister_host(self, token):
+        _check(load_library().racc_hip_unregister_host(self._h, token))
 
     def intersect_streams(self, scene, env, ray_arrays, lane=0):
         """Several host ray streams in ONE launch (≙ what racc::render hands the GPU thread)."""

@@ -381,6 +381,50 @@ def test_sliced_host_path_with_page_locked_streams(gpu_ctx, full):
     assert_bit_exact(outs[2][:50000], ref, "sliced path")
 
 
+
+def test_eight_host_batches_back_to_back_over_the_lanes(gpu_ctx, full):
+    """Round 4: the host RayStream path pipelined ACROSS batches.  Eight different page-locked batches (ragged sizes, 100k ... 1M rays)
+    are enqueued one after the other with racc_hip_intersect_async on rotating lanes — copy-in of batch k+1 beside the kernel of batch
+    k beside the copy-out of batch k-1, all copies of the context on one stream per direction — then waited for; twice, the second
+    time while the lanes' staging arrays are being recycled with other sizes.  Every record of every batch equals the device-resident
+    path's, bit for bit, and a sample of each equals the oracle's."""
+    sc, prim = full["sc"], full["primary"]
+    hits = gpu_ctx.intersect(full["scene"], full["env"], prim)
+    sizes = [1 << 20, 100003, 700079, 1 << 18, 999999, 524288, 65, 800000]
+    batches = [np.ascontiguousarray(synth.diffuse_bounce_rays(sc, prim, hits, n, first_sample=3 + k)) for k, n in enumerate(sizes)]
+    want = []
+    for b in batches:      # the device-resident path, one batch at a time
+        d_r = gpu_ctx.alloc(b.nbytes); d_o = gpu_ctx.alloc(len(b) * 16); d_r.upload(b)
+        gpu_ctx.intersect_device(full["scene"], full["env"], d_r.ptr, d_o.ptr, len(b), lane=0); gpu_ctx.wait(0)
+        want.append(d_o.download(ra.RESULT_DTYPE, len(b))); d_r.free(); d_o.free()
+    outs = [np.zeros(len(b), ra.RESULT_DTYPE) for b in batches]
+    tokens = [gpu_ctx.register_host(a) for a in batches + outs]
+    try:
+        for order in (range(8), (5, 0, 7, 2, 6, 1, 4, 3)):
+            for o in outs:
+                o[:] = 0
+            for i, k in enumerate(order):
+                gpu_ctx.intersect_async(full["scene"], full["env"], batches[k], outs[k], lane=i % gpu_ctx.lanes)
+            gpu_ctx.wait(ra.LANE_AUTO)
+            for k in range(8):
+                assert outs[k].tobytes() == want[k].tobytes(), "batch %d differs from the device-resident path" % k
+        # one lane only: every enqueue first waits for the batch before it (staging reuse) — still complete and in place
+        for o in outs:
+            o[:] = 0
+        for k in range(8):
+            gpu_ctx.intersect_async(full["scene"], full["env"], batches[k], outs[k], lane=2)
+        gpu_ctx.wait(2)
+        for k in range(8):
+            assert outs[k].tobytes() == want[k].tobytes(), "batch %d (one lane)" % k
+    finally:
+        gpu_ctx.wait(ra.LANE_AUTO)
+        for t in tokens:
+            gpu_ctx.unregister_host(t)
+    for k in (0, 2, 6):
+        m = min(len(batches[k]), 40000)
+        assert_bit_exact(outs[k][:m], orc.traverse(full["host"].blobs(), batches[k][:m], env=sc["env"], threads=8), "pipelined host batch %d" % k)
+
+
 def test_soak_random_options_sizes_and_lanes():
     """tools/gpu_fuzz.py: random launch options, kernel variants, batch sizes (1 .. 600k) and 1-4 concurrent lanes with
     back-to-back launches of different sizes on each, every result checked against the oracle."""

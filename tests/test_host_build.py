@@ -173,3 +173,49 @@ def test_group_workers_under_thread_sanitizer():
     assert os.path.exists(exe), "make -C rayaccel_amd/csrc tsan"
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66"))
     assert p.returncode == 0 and "ThreadSanitizer" not in p.stderr, p.stdout + p.stderr[-3000:]
+
+
+def _device_to_reference(dev):
+    """64 B device records (racc_host_scene_device_nodes) back into the reference's node format (Scene.cpp:73-78)."""
+    out = np.zeros(len(dev), ra.engine.GPU_NODE_DTYPE)
+    out["first"], out["last"] = dev[:, 0], dev[:, 1]
+    pl = dev[:, 4:16].view(np.float32)
+    out["leftMin"], out["leftMax"] = pl[:, 0:6:2], pl[:, 1:6:2]
+    out["rightMin"], out["rightMax"] = pl[:, 6:12:2], pl[:, 7:12:2]
+    return out
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_device_node_order_is_the_same_tree(small_scene, small_host, order):
+    """racc_hip_scene_upload re-numbers the nodes (round 4: every 128 B line = a node and the child a ray most likely enters next).
+    The re-numbered records, read back as a reference-format blob, must give the oracle the same hits bit for bit — same boxes, same
+    first/last roles, same leaves — and the line structure must be what the header promises."""
+    dev = small_host.device_nodes(order)
+    n = len(small_host.nodes)
+    inner = lambda r: (r & 0x80000000) != 0
+    used = np.zeros(len(dev), bool)
+    used[0] = True
+    for col in (0, 1):
+        idx = dev[inner(dev[:, col]), col] & 0x7FFFFFFF
+        assert idx.max() < len(dev) and not used[idx].any()       # every record referenced once
+        used[idx] = True
+    assert used.sum() == n and not dev[~used].any()               # the rest is all-zero padding
+    assert len(dev) - n <= max(2, n // 50)
+    rays = np.concatenate([synth.primary_rays(small_scene["camera"], 96, 96)[0], synth.random_rays(6000, seed=3, ymax=30.0)])
+    a = orc.traverse(small_host.blobs(), rays, env=small_scene["env"])
+    b = orc.traverse(dict(small_host.blobs(), nodes=_device_to_reference(dev)), rays, env=small_scene["env"])
+    assert a.tobytes() == b.tobytes()
+    if order == 1:
+        ev = np.arange(0, len(dev) - 1, 2)
+        child_behind = (dev[ev, 0] == (0x80000000 | (ev + 1))) | (dev[ev, 1] == (0x80000000 | (ev + 1)))
+        childless = ~inner(dev[:, 0]) & ~inner(dev[:, 1])
+        assert (child_behind | (childless[ev] & (childless[ev + 1] | ~used[ev + 1]))).all()      # a line = parent + child, or two childless nodes
+        assert child_behind.mean() > 0.5
+        both = inner(dev[ev, 0]) & inner(dev[ev, 1]) & child_behind                                # the larger of two inner children sits behind its parent
+        pl = dev[:, 4:16].view(np.float32)
+        def area(rows, o):
+            x, y, z = (pl[rows, o + 1] - pl[rows, o]).astype(np.float64), (pl[rows, o + 3] - pl[rows, o + 2]).astype(np.float64), (pl[rows, o + 5] - pl[rows, o + 4]).astype(np.float64)
+            return x * y + x * z + y * z
+        rows = ev[both]
+        first_behind = dev[rows, 0] == (0x80000000 | (rows + 1))
+        assert ((area(rows, 0) >= area(rows, 6)) == first_behind).all()
