@@ -31,8 +31,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_MEASURED_GBS = 6290.0      # same guide: float4-copy ceiling
 RAYS_PER_BATCH = 1 << 20
+XL_RAY_SEED = 7
 KERNEL_NAME = "traverseKernelV8"
-PROFILE_DIR = os.path.join("profiles", "r03")      # rocprofv3 summaries of THIS command (tools/profile_bench.sh r03) + microbenchmark outputs
+L2_PEAK_GBS = 34500.0          # same guide, "L2 (per XCD)": 4 MiB x 8, ~34.5 TB/s aggregate
+PCIE_GBS_PER_DIRECTION = 56.0  # page-locked copies on the GPU boxes, one direction alone (tools/microbench/pcie.hip; 49 + 49 with both at once)
+# rocprofv3 summaries of THIS command (tools/profile_bench.sh <round>) + microbenchmark outputs: the latest round's that is committed
+PROFILE_DIR = next(os.path.join("profiles", r) for r in ("r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "derived.json")))
 KERNEL_SOURCES = ("rayaccel_amd/csrc/racc_kernel_v8.inc", "rayaccel_amd/csrc/racc_device.inc")
 CU_CLOCK_HZ, CUS = 2.4e9, 256
 
@@ -69,6 +73,19 @@ def gather_ceiling():
         return None
 
 
+def roofline_core(alg, ms, traffic, ceiling):
+    """The measurement contract's roofline fields for one (kernel, batch): algorithmic bytes per launch over the kernel's launch
+    duration against the HBM peak; `traffic` = the L2-fabric bytes of the same launch from the committed rocprofv3 passes."""
+    if not alg or not ms:
+        return None
+    return {"achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": int(alg), "kernel_ms_avg": round(ms, 4),
+            "fabric_frac_of_hbm_peak": round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+            "fabric_frac_of_hbm_measured_ceiling": round(traffic / (ms * 1e-3) / 1e9 / HBM_MEASURED_GBS, 4) if traffic else None,
+            "l1_gather_frac": round(alg / (ms * 1e-3) / (CUS * CU_CLOCK_HZ) / ceiling, 4) if ceiling else None}
+
+
 def usable_cores():
     """Host cores this process may really use: CPU affinity capped by the cgroup CPU quota (the GPU boxes expose 256
     logical CPUs but grant 16 CPUs of quota; more threads than that only oversubscribes)."""
@@ -99,8 +116,10 @@ def main():
                     help="N > 1: also time the K steps with the RCCL all-gather of every step's hit records (racc_hip_allgather_results); implied by --mode strong")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (profiling runs)")
-    ap.add_argument("--workload", choices=("diffuse", "coherent"), default="diffuse",
-                    help="diffuse (default, the headline): 1M first-bounce diffuse rays per step (configs[2]); coherent: the 1M primary rays (configs[1]) — profiling runs of that config")
+    ap.add_argument("--workload", choices=("diffuse", "coherent", "xl", "xl_diffuse"), default="diffuse",
+                    help="diffuse (default, the headline): 1M first-bounce diffuse rays per step (configs[2]); coherent: the 1M primary rays (configs[1]); "
+                         "xl / xl_diffuse: battlefield-synth-XL (25 M triangles, 1.3 GB on the device: past the Infinity Cache) with 1M incoherent rays / "
+                         "its camera's 1M first-bounce diffuse rays — profiling runs of those configs")
     ap.add_argument("--grid", type=int, default=700, help="height-field resolution of battlefield-synth (700 = full)")
     ap.add_argument("--engine-opts", default="", help="JSON dict of racc_hip_options overrides (kernel A/B and profiling runs only)")
     args = ap.parse_args()
@@ -147,7 +166,11 @@ def main():
 
     # ---- inputs (synthetic stand-in: the reference's battlefield.bin is unavailable) ----------
     full = args.grid == 700
-    sc = synth.battlefield_synth() if full else synth.battlefield_synth(grid=args.grid, boxes=args.grid * 6, quads=args.grid * 28)
+    xl_run = args.workload in ("xl", "xl_diffuse")
+    if xl_run:
+        sc = synth.battlefield_synth_xl() if full else synth.battlefield_synth_xl(grid=args.grid)
+    else:
+        sc = synth.battlefield_synth() if full else synth.battlefield_synth(grid=args.grid, boxes=args.grid * 6, quads=args.grid * 28)
     host = ra.HostScene(sc["vertices"], sc["indices"])
     engine_opts = dict(time_kernels=1)
     engine_opts.update(json.loads(args.engine_opts) if args.engine_opts else {})
@@ -160,6 +183,9 @@ def main():
     primary_hits = ctx.intersect(scene, env, primary)                       # GPU path, host buffers
     if args.workload == "coherent":
         bounce = primary                       # configs[1]: the timed batch is the coherent primary batch itself
+        total_rays = world * len(bounce)
+    elif args.workload == "xl":
+        bounce = synth.random_rays(RAYS_PER_BATCH, XL_RAY_SEED + rank)      # incoherent: origins and directions uniform over the scene
         total_rays = world * len(bounce)
     elif args.mode == "weak":
         bounce = synth.diffuse_bounce_rays(sc, primary, primary_hits, RAYS_PER_BATCH, first_sample=rank)
@@ -196,9 +222,13 @@ def main():
     # duration settles only after the GPU has been busy for ~15 ms (10 launches: 0.386 ms, 100: 0.373; rocprofv3's one-lane
     # trace of the committed profile: 0.371), so 60 launches are timed and the mean of the last 30 is reported.
     # (every rank does it: at N > 1 all GPUs enter the timed region in the same state, and the line reports rank 0's)
+    # These launches run BEFORE the warm-up steps and are reported as `pre_timed_launches`: the GPU's clocks are up when the timed
+    # region starts (RACC_BENCH_ISO_LAUNCHES=0 skips them — the profiling passes do, so that their last K traversal dispatches are the K steps).
     iso_n = int(os.environ.get("RACC_BENCH_ISO_LAUNCHES", "60"))
-    iso_all = ctx.intersect_device_timed(scene, env, d_rays.data_ptr(), outs[-1].data_ptr(), n, iso_n)
-    iso_ms = float(np.mean(iso_all[len(iso_all) // 2:]))
+    iso_ms = None
+    if iso_n > 0:
+        iso_all = ctx.intersect_device_timed(scene, env, d_rays.data_ptr(), outs[-1].data_ptr(), n, iso_n)
+        iso_ms = float(np.mean(iso_all[len(iso_all) // 2:]))
 
     if args.warmup:
         run_overlapped(args.warmup)
@@ -288,23 +318,49 @@ def main():
         for _ in range(3):
             ctx.intersect(scene, env, bounce, res_host)
         extras["host_buffers_pcie_inclusive_mrays_per_s"] = round(3 * n / (time.perf_counter() - t1) / 1e6, 1)
-        # the same with the two host arrays page-locked (racc_hip_register_host, what racc::createContext does with its
-        # stream block): the copies go by DMA and big batches are sliced so that copies run beside kernels
-        lib = ra.load_library()
+        # The same with the host arrays page-locked (racc_hip_register_host, what racc::createContext does with its stream block): the
+        # copies go by DMA.  (a) one batch at a time through the blocking entry — cut into slices so that copies run beside kernels;
+        # (b) eight batches issued back to back with racc_hip_intersect_async on rotating lanes and waited for at the end — the engine
+        # keeps copy-in, kernels and copy-out of consecutive batches in flight (racc_hostpath.inc).  PCIe is full duplex: the two
+        # directions are reported separately, each against what one direction delivers alone on this box.
         ray_host = np.ascontiguousarray(bounce)
-        if lib.racc_hip_register_host(ctx._h, ray_host.ctypes.data, ray_host.nbytes) == 0 and \
-                lib.racc_hip_register_host(ctx._h, res_host.ctypes.data, res_host.nbytes) == 0:
-            ctx.intersect(scene, env, ray_host, res_host)
+        host_outs = [np.zeros(n, ra.RESULT_DTYPE) for _ in range(8)]
+        tokens = [ctx.register_host(a) for a in [ray_host] + host_outs]
+        try:
+            ctx.intersect(scene, env, ray_host, host_outs[0])
             t1 = time.perf_counter()
             for _ in range(5):
-                ctx.intersect(scene, env, ray_host, res_host)
+                ctx.intersect(scene, env, ray_host, host_outs[0])
             dt = (time.perf_counter() - t1) / 5
-            extras["host_buffers_page_locked_mrays_per_s"] = round(n / dt / 1e6, 1)
-            extras["host_buffers_page_locked_pcie_gbs"] = round(n * 48 / dt / 1e9, 1)      # 32 B in + 16 B out per ray; link: ~63 GB/s per direction
-            if not np.array_equal(res_host.view(np.uint32).reshape(-1, 4), d_ref_bits.cpu().numpy().view(np.uint32)):
+            want_bits = d_ref_bits.cpu().numpy().view(np.uint32)
+            if not np.array_equal(host_outs[0].view(np.uint32).reshape(-1, 4), want_bits):
                 sys.exit("bench: the sliced host-buffer path changed the results")
-            lib.racc_hip_unregister_host(ctx._h, ray_host.ctypes.data)
-            lib.racc_hip_unregister_host(ctx._h, res_host.ctypes.data)
+            extras["host_buffers_page_locked"] = {"one_batch_at_a_time_mrays_per_s": round(n / dt / 1e6, 1),
+                                                  "h2d_gbs": round(n * 32 / dt / 1e9, 1), "d2h_gbs": round(n * 16 / dt / 1e9, 1)}
+
+            def pipelined(reps):
+                for r in range(reps):
+                    for k in range(8):
+                        ctx.intersect_async(scene, env, ray_host, host_outs[k], lane=k % lanes)
+                ctx.wait(ra.LANE_AUTO)
+            pipelined(1)
+            for o in host_outs:
+                o[:] = 0
+            t1 = time.perf_counter()
+            pipelined(2)
+            dt = (time.perf_counter() - t1) / 16
+            if any(not np.array_equal(o.view(np.uint32).reshape(-1, 4), want_bits) for o in host_outs):
+                sys.exit("bench: host batches issued back to back over the lanes changed the results")
+            extras["host_buffers_page_locked"]["back_to_back"] = {
+                "mrays_per_s": round(n / dt / 1e6, 1), "batches": 16, "lanes": lanes,
+                "h2d_gbs": round(n * 32 / dt / 1e9, 1), "d2h_gbs": round(n * 16 / dt / 1e9, 1),
+                "h2d_frac_of_one_direction": round(n * 32 / dt / 1e9 / PCIE_GBS_PER_DIRECTION, 3), "d2h_frac_of_one_direction": round(n * 16 / dt / 1e9 / PCIE_GBS_PER_DIRECTION, 3),
+                "link_gbs_per_direction": PCIE_GBS_PER_DIRECTION,
+                "how": "16 page-locked 1M-ray batches, racc_hip_intersect_async on rotating lanes, one racc_hip_wait at the end; every record compared with the device-resident path's"}
+        finally:
+            ctx.wait(ra.LANE_AUTO)
+            for t in tokens:
+                ctx.unregister_host(t)
 
         # Batch-size scaling of the traversal kernel (same diffuse rays, 8 sample sets): T(N) = fixed + per-ray cost.
         if world == 1 and full and args.mode == "weak":
@@ -374,11 +430,62 @@ def main():
             finally:
                 os.unlink(tmp.name)
 
+    # ---- battlefield-synth-XL: the regime in which HBM can bind (rank 0, N = 1) --------------------
+    xl = None
+    if rank == 0 and world == 1 and full and args.mode == "weak" and args.workload == "diffuse" and not args.no_extras:
+        xl = {}
+        prof_x = committed_profile() or {}
+        sx = synth.battlefield_synth_xl()
+        hx = ra.HostScene(sx["vertices"], sx["indices"])
+        scene_x = ctx.upload_scene(hx.nodes, hx.pairs, hx.remap)
+        env_x = ctx.create_environment(sx["env"])
+        hits_x = ctx.intersect(scene_x, env_x, primary)
+        xl_batches = (("xl", "1M incoherent rays (origins and directions uniform over the scene)", synth.random_rays(RAYS_PER_BATCH, XL_RAY_SEED)),
+                      ("xl_diffuse", "1M first-bounce diffuse rays of the bench camera", synth.diffuse_bounce_rays(sx, primary, hits_x, RAYS_PER_BATCH)))
+        for key, what, rays_x in xl_batches:
+            d_rx = torch.from_numpy(rays_x.view(np.float32).reshape(len(rays_x), 8).copy()).cuda()
+            d_ox = torch.zeros((len(rays_x), 4), dtype=torch.float32, device="cuda")
+            ms_x = ctx.intersect_device_timed(scene_x, env_x, d_rx.data_ptr(), d_ox.data_ptr(), len(rays_x), 40)
+            ms_x = float(np.mean(ms_x[len(ms_x) // 2:]))
+            alg_x, src_x = None, None
+            if not args.no_cpu_baseline:
+                from oracle import oracle            # checker only
+                ref_x, nv_x, np_x, _ = oracle.traverse(hx.blobs(), rays_x, env=sx["env"], counters=True)
+                alg_x, src_x = oracle.algorithmic_bytes(ref_x, nv_x, np_x), "oracle counters, live"
+                got_x = d_ox.cpu().numpy().view(ra.RESULT_DTYPE).reshape(-1)
+                hit_x = ref_x["triangle"] != 0xFFFFFFFF
+                if not np.array_equal(got_x["triangle"], ref_x["triangle"]) or any(
+                        not np.array_equal(got_x[f][hit_x].view(np.uint32), ref_x[f][hit_x].view(np.uint32)) for f in ("t", "u", "v")):
+                    sys.exit("bench: GPU results on battlefield-synth-XL (%s) differ from the oracle — refusing to report a number" % key)
+            else:
+                try:
+                    with open(os.path.join(ROOT, "tests", "golden", "algorithmic_bytes.json")) as f:
+                        alg_x, src_x = json.load(f)[key + "_1M"]["bytes"], "tests/golden/algorithmic_bytes.json"
+                except (OSError, KeyError, ValueError):
+                    pass
+            px = prof_x.get(key, {})
+            r = roofline_core(alg_x, ms_x, px.get("fabric_bytes_per_launch"), gather_ceiling()) or {"kernel_ms_avg": round(ms_x, 4)}
+            r.update({"workload": "battlefield-synth-XL, %d triangles, %s" % (len(sx["indices"]), what), "mrays_per_s": round(len(rays_x) / ms_x / 1e3, 1),
+                      "algorithmic_source": src_x, "device_bytes": int(scene_x.info["device_bytes"]),
+                      "traffic_frac_of_algorithmic": round(px["fabric_bytes_per_launch"] / alg_x, 4) if (px.get("fabric_bytes_per_launch") and alg_x) else None,
+                      "limiter": {q: px.get(q) for q in ("td_busy_frac", "ta_busy_frac", "valu_busy_frac", "l2_hit_rate", "kernel_ms_isolated", "fetch_bytes_per_launch", "write_bytes_per_launch")} if px else None})
+            xl[key] = r
+            del d_rx, d_ox
+        scene_x.destroy(); env_x.destroy()
+        del hx, sx
+
     # ---- roofline + CPU baseline (rank 0) --------------------------------------------------------
     roofline, cpu_baseline = None, None
     if rank == 0:
         avg_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else None
         alg_bytes, src = None, None
+        golden = {}
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "algorithmic_bytes.json")) as f:
+                golden = json.load(f)
+        except (OSError, ValueError):
+            pass
+        golden_key = {"diffuse": "diffuse_1M_sample0", "coherent": "coherent_1M", "xl": "xl_1M", "xl_diffuse": "xl_diffuse_1M"}[args.workload]
         if not args.no_cpu_baseline and world == 1 and args.mode == "weak":       # the CPU legs run at N=1 only
             from oracle import oracle            # checker / CPU leg only; never on the product path
             blobs = host.blobs()
@@ -404,7 +511,7 @@ def main():
                 times.append((time.perf_counter() - t1) / repeat)
             cpu_baseline = {"value": round(n / float(np.median(times)) / 1e6, 2), "unit": "Mrays/s", "cores": threads,
                             "kind": "port",
-                            "sample": "the full 1,048,576-ray diffuse batch, %d passes per timing x 3 timings (median), %d pthreads x "
+                            "sample": "the full 1,048,576-ray batch of the timed workload, %d passes per timing x 3 timings (median), %d pthreads x "
                                       "1024-ray slices; SCALAR BVH2 port of the reference's traversal, not Embree-class "
                                       "(the reference's CPU path is binary-only Embree 2.x bvh8/AVX2, unavailable here; "
                                       "oracle/embree_adapter.py adds a row when a system Embree exists)" % (repeat, threads)}
@@ -418,7 +525,7 @@ def main():
             # same GPU and batch, launched as the reference launches it (work-groups of 8, enqueue + clFinish).
             try:
                 from oracle import ref_kernel
-                if ref_kernel.built():
+                if ref_kernel.built() and not xl_run:
                     ref_res, ref_t = ref_kernel.run(blobs, bounce, sc["env"], repeats=5)
                     hit = ref["triangle"] != 0xFFFFFFFF
                     agree = float((ref_res["triangle"][hit] == ref["triangle"][hit]).mean())
@@ -428,58 +535,48 @@ def main():
                         "what": "Kernels.h `traversal`, -cl-fast-relaxed-math, local size 8, same 1M-ray diffuse batch, enqueue + clFinish"}
             except Exception as e:   # noqa: BLE001 - a missing OpenCL runtime must not fail the bench
                 extras["reference_opencl_kernel_on_this_gpu"] = {"error": str(e)[:200]}
-        else:
-            try:
-                with open(os.path.join(ROOT, "tests", "golden", "algorithmic_bytes.json")) as f:
-                    alg_bytes = json.load(f)["diffuse_1M_sample0"]["bytes"] if (full and args.mode == "weak") else None
-                    src = "tests/golden/algorithmic_bytes.json"
-            except (OSError, KeyError, ValueError):
-                pass
-        golden = {}
-        try:
-            with open(os.path.join(ROOT, "tests", "golden", "algorithmic_bytes.json")) as f:
-                golden = json.load(f)
-        except (OSError, ValueError):
-            pass
-        if args.workload == "coherent" and not alg_bytes:
-            alg_bytes, src = (golden.get("coherent_1M") or {}).get("bytes") if full else None, "tests/golden/algorithmic_bytes.json"
-        prof = None
+        elif full and args.mode == "weak":
+            alg_bytes, src = (golden.get(golden_key) or {}).get("bytes"), "tests/golden/algorithmic_bytes.json"
+        prof = committed_profile()
+        on_profiled_workload = bool(prof and full and args.mode == "weak")
+        pw = (prof or {}).get(args.workload, {}) if on_profiled_workload else {}
+        traffic = pw.get("fabric_bytes_per_launch")
+        step_s = elapsed / args.steps
+        ceiling = gather_ceiling()
         if iso_ms:
             # The contract's roofline: `achieved` = the ALGORITHMIC bytes of SURVEY §8(d) per launch (every node / pair the reference's
             # traversal order touches, counted by the oracle) over the traversal kernel's launch duration (HIP events, the kernel alone
-            # on the GPU), against the 8 TB/s of HBM.  The fraction comes out ABOVE 1: the 55 MB scene lives in the L2s and the
-            # Infinity Cache, which serve nearly all of those bytes — the work is done (every record of the timed batch is compared
-            # with the oracle above), HBM is simply not what bounds this kernel.  `traffic` = what did cross the L2-fabric boundary
-            # per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, same isolated mode, committed profile); `l1_gather` = the same
-            # algorithmic bytes against the ceiling they can be held to, the CU's vector-memory return path, measured by a
-            # microbenchmark whose output is committed beside the profile; `limiter` = the counters that say what binds it.
-            prof = committed_profile()
-            on_profiled_workload = bool(prof and full and args.mode == "weak")
-            pw = (prof or {}).get("coherent" if args.workload == "coherent" else "diffuse", {}) if on_profiled_workload else {}
-            traffic = pw.get("fabric_bytes_per_launch")
-            step_s = elapsed / args.steps
-            ceiling = gather_ceiling()
-
-            def core(alg, ms, tr):
-                if not alg or not ms:
-                    return None
-                return {"achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr,
-                        "algorithmic_bytes_per_launch": int(alg), "kernel_ms_avg": round(ms, 4),
-                        "fabric_frac_of_hbm_peak": round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr else None,
-                        "l1_gather_frac": round(alg / (ms * 1e-3) / (CUS * CU_CLOCK_HZ) / ceiling, 4) if ceiling else None}
-            c = core(alg_bytes, iso_ms, traffic) or {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": traffic, "kernel_ms_avg": round(iso_ms, 4)}
+            # on the GPU), against the 8 TB/s of HBM.  On battlefield-synth the fraction comes out ABOVE 1: the 55 MB scene lives in the
+            # L2s and the Infinity Cache, which serve nearly all of those bytes — the work is done (every record of the timed batch is
+            # compared with the oracle above), HBM is simply not what bounds this kernel there: `bound_actual` holds the same bytes to
+            # the two levels they do pass through (the L2s' aggregate bandwidth; the CU's vector-memory return path, measured by a
+            # committed microbenchmark), `traffic` = what did cross the L2-fabric boundary per launch (rocprofv3 FETCH_SIZE x2 +
+            # WRITE_SIZE, same isolated mode, committed profile), `limiter` = the counters that say what binds it.  Where HBM CAN bind
+            # is `roofline_by_config["battlefield-synth-XL ..."]`: 1.3 GB of scene, incoherent rays, frac < 1, traffic > the algorithmic bytes.
+            c = roofline_core(alg_bytes, iso_ms, traffic, ceiling) or {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": traffic, "kernel_ms_avg": round(iso_ms, 4)}
             roofline = {"bound": "hbm"}
             roofline.update(c)
             roofline.update({
                 "kernel": KERNEL_NAME, "algorithmic_source": src,
-                "kernel_ms_avg_note": "HIP events around the traversal kernel on the stream it is launched on, the kernel alone on the GPU (10 launches after the timed region); "
+                "kernel_ms_avg_note": "HIP events around the traversal kernel on the stream it is launched on, the kernel alone on the GPU, one launch at a time: "
+                                      "%d launches BEFORE the warm-up steps (`pre_timed_launches`), mean of the last %d; "
                                       "rocprofv3 --kernel-trace of the same command with one lane and no chaining: %s ms (%s/kernel_stats_one_lane.csv)" % (
-                                          round(pw["kernel_ms_isolated"], 4) if pw.get("kernel_ms_isolated") else "n/a", PROFILE_DIR),
-                "reading": "frac > 1 because L2 and the Infinity Cache serve the algorithmic bytes; what crossed the L2-fabric boundary is `traffic` "
-                           "(%s of the algorithmic bytes), %s of the HBM peak" % (
-                               ("%.1f %%" % (100.0 * traffic / alg_bytes)) if (traffic and alg_bytes) else "n/a",
-                               ("%.1f %%" % (100.0 * c["fabric_frac_of_hbm_peak"])) if c.get("fabric_frac_of_hbm_peak") else "n/a"),
+                                          iso_n, iso_n - iso_n // 2, round(pw["kernel_ms_isolated"], 4) if pw.get("kernel_ms_isolated") else "n/a", PROFILE_DIR),
+                "frac_is": "algorithmic bytes / kernel duration / HBM peak — NOT a utilisation of HBM when it exceeds `traffic`'s share: see bound_actual",
+                "bound_actual": None if not alg_bytes else {
+                    "what": "the algorithmic bytes against the levels they pass through on this scene (cache-resident: L2 hit rate %s)" % pw.get("l2_hit_rate", "n/a"),
+                    "l2_aggregate": {"peak_gbs": L2_PEAK_GBS, "frac_isolated_launch": round(alg_bytes / (iso_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4),
+                                     "frac_timed_region": round(alg_bytes / step_s / 1e9 / L2_PEAK_GBS, 4)},
+                    "cu_gather_path": None if not ceiling else {
+                        "measured_ceiling_B_per_clk_per_CU": ceiling,
+                        "frac_isolated_launch": round(alg_bytes / (iso_ms * 1e-3) / (CUS * CU_CLOCK_HZ) / ceiling, 4),
+                        "frac_timed_region": round(alg_bytes / step_s / (CUS * CU_CLOCK_HZ) / ceiling, 4),
+                        "frac_steady_state": (round(alg_bytes / ((1 << 20) / (extras["batch_scaling"]["steady_state_mrays_per_s"] * 1e6)) / (CUS * CU_CLOCK_HZ) / ceiling, 4)
+                                              if "batch_scaling" in extras else None),
+                        "note": "256 CUs x 2.4 GHz; ceiling = tools/microbench/gather64.hip mode 2 (64 random 64 B records per wave through quad-cooperative LDS-DMA, "
+                                "6 waves/SIMD), output in %s/gather64.txt" % PROFILE_DIR},
+                    "hbm": {"peak_gbs": HBM_PEAK_GBS, "fabric_traffic_frac_of_peak": c.get("fabric_frac_of_hbm_peak"),
+                            "traffic_frac_of_algorithmic": round(traffic / alg_bytes, 4) if traffic else None}},
                 "traffic_what": "L2-miss / fabric bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes, gfx950 correction of the guide), "
                                 "the kernel alone on the GPU as for `achieved`; includes Infinity-Cache hits, so an upper bound of HBM traffic; %s/pmc_summary.json" % PROFILE_DIR,
                 # the timed region: launches are chained and overlap, so the rate is bytes per launch over the time the region spends per launch
@@ -490,45 +587,44 @@ def main():
                     "kernel_event_note": "HIP events around every traversal kernel of the timed region: chained launches — the first kernels of a sequence work "
                                          "through the later batches, whose own kernels then find nothing left — so this is not a per-launch duration",
                     "fabric_bytes_per_step_chained": pw.get("fabric_bytes_per_step_chained")},
-                # The algorithmic bytes DO pass through each CU's vector-memory return path (every node visit's 64 B, every pair's
-                # 48 B): bytes per clock per CU against the best rate a pure gather of random 64 B records reaches on this part.
-                "l1_gather": None if not (alg_bytes and ceiling) else {
-                    "isolated_launch_B_per_clk_per_CU": round(alg_bytes / (iso_ms * 1e-3) / (CUS * CU_CLOCK_HZ), 2),
-                    "timed_region_B_per_clk_per_CU": round(alg_bytes / step_s / (CUS * CU_CLOCK_HZ), 2),
-                    "steady_state_B_per_clk_per_CU": (round(alg_bytes / ((1 << 20) / (extras["batch_scaling"]["steady_state_mrays_per_s"] * 1e6)) / (CUS * CU_CLOCK_HZ), 2)
-                                                      if "batch_scaling" in extras else None),
-                    "measured_gather_ceiling_B_per_clk_per_CU": ceiling,
-                    "frac_isolated_launch": round(alg_bytes / (iso_ms * 1e-3) / (CUS * CU_CLOCK_HZ) / ceiling, 4),
-                    "frac_timed_region": round(alg_bytes / step_s / (CUS * CU_CLOCK_HZ) / ceiling, 4),
-                    "note": "256 CUs x 2.4 GHz; ceiling = tools/microbench/gather64.hip mode 2 (64 random 64 B records per wave through quad-cooperative LDS-DMA, "
-                            "6 waves/SIMD), output in %s/gather64.txt" % PROFILE_DIR},
                 "limiter": None if not pw else {k: pw.get(k) for k in (
                     "bound", "td_busy_frac", "ta_busy_frac", "valu_busy_frac", "issue_slot_frac", "valu_lane_util", "salu_share",
-                    "l2_hit_rate", "vmem_rd_insts_per_ray", "valu_insts_per_ray", "kernel_ms_isolated")},
+                    "l2_hit_rate", "vmem_rd_insts_per_ray", "valu_insts_per_ray", "kernel_ms_isolated", "write_x_compulsory")},
                 "profile_source": (prof or {}).get("source"),
                 "profile_stale": bool(prof["stale"]) if prof else None})
-            # configs[1] (coherent primaries) beside configs[2] (the headline): same definitions
+            # the other configs beside configs[2] (the headline): same definitions
             if on_profiled_workload and args.workload == "diffuse" and "coherent_1M" in extras:
                 pc = prof.get("coherent", {})
-                by = {"configs[2] 1M first-bounce diffuse": {k: roofline.get(k) for k in ("achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel_ms_avg", "fabric_frac_of_hbm_peak", "l1_gather_frac")},
-                      "configs[1] 1M coherent primaries": core((golden.get("coherent_1M") or {}).get("bytes"), extras["coherent_1M"]["ms_per_step"], pc.get("fabric_bytes_per_launch"))}
+                keys = ("achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel_ms_avg", "fabric_frac_of_hbm_peak", "l1_gather_frac")
+                by = {"configs[2] 1M first-bounce diffuse": {k: roofline.get(k) for k in keys},
+                      "configs[1] 1M coherent primaries": roofline_core((golden.get("coherent_1M") or {}).get("bytes"), extras["coherent_1M"]["ms_per_step"], pc.get("fabric_bytes_per_launch"), ceiling)}
                 for k, pk in (("configs[2] 1M first-bounce diffuse", pw), ("configs[1] 1M coherent primaries", pc)):
                     if by[k] is not None:
                         by[k]["limiter"] = {q: pk.get(q) for q in ("td_busy_frac", "valu_busy_frac", "valu_lane_util", "l2_hit_rate", "vmem_rd_insts_per_ray", "valu_insts_per_ray")} if pk else None
+                if xl:
+                    by["battlefield-synth-XL 1M incoherent rays (HBM can bind here)"] = xl.get("xl")
+                    by["battlefield-synth-XL 1M first-bounce diffuse (bench camera)"] = xl.get("xl_diffuse")
                 extras["roofline_by_config"] = by
             if prof and prof["stale"]:
                 print("bench: %s was taken with other kernel sources; re-run tools/profile_bench.sh + tools/summarize_profile.py" % PROFILE_DIR, file=sys.stderr)
 
+        scene_label = ("battlefield-synth-XL" if xl_run else "battlefield-synth") + " (stand-in; reference scene unavailable), %d triangles, " % len(sc["indices"])
+        if args.workload == "xl":
+            workload_text = scene_label + "1M incoherent rays (uniform origins and directions) per GPU per step — a profiling run, not a BASELINE config"
+        elif args.workload == "coherent":
+            workload_text = scene_label + "1M coherent primary rays per GPU per step (BASELINE configs[1]), steps issued back to back over %d engine lanes" % ctx.auto_lanes
+        elif args.mode == "weak":
+            workload_text = scene_label + "1M 1st-bounce diffuse rays per GPU per step (BASELINE configs[2]/[3]), steps issued back to back over %d engine lanes" % ctx.auto_lanes
+        else:
+            workload_text = scene_label + "ONE 8M-ray 1st-bounce diffuse batch per step cut into %d contiguous shards (BASELINE configs[3])" % world
         line = {
             "metric": "Mrays/s", "value": round(value, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "pre_timed_launches": iso_n,      # isolated launches (the roofline's kernel duration) issued before the warm-up steps: they also bring the clocks up
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": args.mode, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("battlefield-synth (stand-in; reference scene unavailable), %d triangles, " % len(sc["indices"])) +
-                                   (("1M coherent primary rays per GPU per step (BASELINE configs[1]), steps issued back to back over %d engine lanes" % ctx.auto_lanes) if args.workload == "coherent" else
-                                    "1M 1st-bounce diffuse rays per GPU per step (BASELINE configs[2]/[3]), steps issued back to back over %d engine lanes" % ctx.auto_lanes
-                                    if args.mode == "weak" else "ONE 8M-ray 1st-bounce diffuse batch per step cut into %d contiguous shards (BASELINE configs[3])" % world),
+            "config": {"workload": workload_text,
                        "rays_per_gpu": n, "scene": sc["name"], "parallelism": "rays sharded x%d, scene replicated" % world,
                        "grid_blocks": launch["grid_blocks"], "waves_per_simd": launch["waves_per_simd"], "lanes": lanes,
                        "lanes_in_rotation": ctx.auto_lanes, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},

@@ -131,6 +131,21 @@ def battlefield_synth(grid=700, boxes=4096, quads=20000, seed=SCENE_SEED, extent
                 name="battlefield-synth(grid=%d,boxes=%d,quads=%d,seed=0x%X)" % (grid, boxes, quads, seed))
 
 
+XL_GRID = 3400
+
+
+def battlefield_synth_xl(grid=XL_GRID, seed=SCENE_SEED):
+    """battlefield-synth-XL (round 4): the same generator scaled past the MI355X's 256 MiB Infinity Cache — a 3400 x 3400-quad
+    height-field, 96,632 boxes, 471,836 thin quads = 25,223,256 triangles, i.e. 594 MB of nodes + 623 MB of pairs + 104 MB of remap on
+    the device (the reference format holds < 2^24 pairs, Scene.cpp:294-312: ~32 M triangles is its ceiling).  battlefield-synth
+    (55 MB) lives in the L2s and the Infinity Cache after the first launch, so no roofline can bind there; this one is where the
+    contractual HBM yard-stick is tested.  Same camera, same environment."""
+    k = (grid / 700.0) ** 2
+    sc = battlefield_synth(grid=grid, boxes=int(4096 * k) // 4 * 4, quads=int(20000 * k), seed=seed)
+    sc["name"] = "battlefield-synth-XL(" + sc["name"].split("(", 1)[1]
+    return sc
+
+
 def environment_synth(width=512, height=256):
     """512x256 RGBA32F gradient sky + sun lobe."""
     v, u = np.meshgrid((np.arange(height) + 0.5) / height, (np.arange(width) + 0.5) / width, indexing="ij")

@@ -18,7 +18,7 @@ batches = [np.ascontiguousarray(np.concatenate([synth.diffuse_bounce_rays(sc, pr
 refs = [orc.traverse(host.blobs(), b, env=sc["env"], threads=16) for b in batches]
 outs = [np.zeros(n, ra.RESULT_DTYPE) for _ in range(nb)]
 lib = ra.load_library()
-for lanes in (1, 2, 3, 4, 6):
+for lanes in ([int(os.environ['RACC_HOSTPIPE_LANES'])] if os.environ.get('RACC_HOSTPIPE_LANES') else (2, 3, 4, 5, 6, 8)):
     with ra.Context(device=0, lanes=lanes) as ctx:
         scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
         env = ctx.create_environment(sc["env"])

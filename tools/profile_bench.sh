@@ -9,7 +9,11 @@
 #   pmcc_<i>              the same for the coherent primary batch (--workload coherent), fewer sets
 #   pmcv_<i>              the same for the compressed 4-wide kernel (kernel_variant 50), diffuse batch, fewer sets
 #   pmcx_<i>              FETCH_SIZE / WRITE_SIZE in the timed region's own mode (three lanes, chained); rocprofv3 serialises dispatches under --pmc
-TAG=${1:-r03}
+#   pmcxl_<i>, pmcxd_<i>  battlefield-synth-XL (1.3 GB on the device: past the Infinity Cache), 1M incoherent rays / the camera's 1M diffuse rays, one lane, no chaining
+# RACC_BENCH_ISO_LAUNCHES=0: no isolated launches before the warm-up, so the LAST 20 traversal dispatches of every pass are the 20 timed
+# steps (tools/summarize_profile.py selects them from the end; round 3's passes picked rows 4..23, which fell inside the isolated block).
+export RACC_BENCH_ISO_LAUNCHES=0
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -30,7 +34,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \
            "GRBM_GUI_ACTIVE GRBM_COUNT" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
-           "TA_TA_BUSY_sum TD_TD_BUSY_sum" "TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum"; do
+           "TA_TA_BUSY_sum TD_TD_BUSY_sum" "TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   i=$((i+1)); pass pmc $i "$set" --engine-opts "$ONE"
 done
 i=0
@@ -42,6 +46,22 @@ done
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1)); pass pmcx $i "$set"
+done
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_lane_xl" -- $CMD --workload xl --engine-opts "$ONE" > "$OUT/stats_one_lane_xl.log" 2>&1
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_lane_xl_diffuse" -- $CMD --workload xl_diffuse --engine-opts "$ONE" > "$OUT/stats_one_lane_xl_diffuse.log" 2>&1
+passxl() {   # the XL scene takes ~20 s to build: its own, longer timeout
+  local pre=$1 i=$2 set=$3; shift 3
+  timeout -k 5 400 rocprofv3 --pmc $set --output-format csv -d "$OUT/${pre}_$i" -- $CMD "$@" > "$OUT/${pre}_$i.log" 2>&1 || echo "pass ${pre}_$i ($set) failed"
+}
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY" \
+           "GRBM_GUI_ACTIVE GRBM_COUNT" "TA_TA_BUSY_sum TD_TD_BUSY_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+  i=$((i+1)); passxl pmcxl $i "$set" --workload xl --engine-opts "$ONE"
+done
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE GRBM_COUNT" "TA_TA_BUSY_sum TD_TD_BUSY_sum"; do
+  i=$((i+1)); passxl pmcxd $i "$set" --workload xl_diffuse --engine-opts "$ONE"
 done
 find "$OUT" -name "*.csv" | wc -l
 du -sh "$OUT"

@@ -4,14 +4,16 @@
   profiles/<tag>/pmc_summary.json            mean of every counter over the 20 timed launches (PMC passes serialise kernels)
   profiles/<tag>/derived.json                what bench.py puts into its `roofline` object, each figure with its formula
 
-Launch order of `bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 3` among traverseKernel dispatches: [0] primary
-batch through the host-buffer path, [1..3] warm-up, [4..23] the 20 timed diffuse launches."""
+Launch order of `bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 3` among traverseKernel dispatches: the primary batch
+through the host-buffer path, (isolated launches unless RACC_BENCH_ISO_LAUNCHES=0 — tools/profile_bench.sh sets it), 3 warm-up steps,
+the 20 timed launches: the LAST 20 traversal dispatches of a pass, which is how they are selected here (round 3 took rows 4..23 and
+landed inside the isolated block: ADVICE r03)."""
 import collections, csv, glob, hashlib, json, os, shutil, sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CUS, SIMDS, XCDS = 256, 1024, 8
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
@@ -29,15 +31,18 @@ def trace_durations(sub):
     rows = [r for r in csv.DictReader(open(t)) if "traverseKernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
-    span = (max(int(r["End_Timestamp"]) for r in rows[4:24]) - min(int(r["Start_Timestamp"]) for r in rows[4:24])) / 1e6
-    return rows, dict(kernel=rows[0]["Kernel_Name"], timed_mean_ms=float(np.mean(dur[4:24])), timed_min_ms=float(np.min(dur[4:24])),
+    if len(rows) < 20:
+        return rows, None
+    timed = rows[-20:]
+    span = (max(int(r["End_Timestamp"]) for r in timed) - min(int(r["Start_Timestamp"]) for r in timed)) / 1e6
+    return rows, dict(kernel=timed[0]["Kernel_Name"], timed_mean_ms=float(np.mean(dur[-20:])), timed_min_ms=float(np.min(dur[-20:])),
                       timed_span_ms_per_launch=span / 20.0, launches=len(rows),
-                      vgpr=rows[4].get("VGPR_Count"), sgpr=rows[4].get("SGPR_Count"), lds=rows[4].get("LDS_Block_Size"),
-                      grid=rows[4].get("Grid_Size"), workgroup=rows[4].get("Workgroup_Size"))
+                      vgpr=timed[0].get("VGPR_Count"), sgpr=timed[0].get("SGPR_Count"), lds=timed[0].get("LDS_Block_Size"),
+                      grid=timed[0].get("Grid_Size"), workgroup=timed[0].get("Workgroup_Size"))
 
 
 def counters(prefix, sum_timed=False):
-    """Mean over the 20 timed launches (dispatches 4..23 among the traversal kernels) of every counter of the passes <prefix>_<i>;
+    """Mean over the 20 timed launches (the last 20 traversal dispatches of a pass) of every counter of the passes <prefix>_<i>;
     sum_timed: the SUM over those dispatches / 20 (chained launches: one kernel may do several batches' work, the others none)."""
     res = {}
     for d in sorted(filter(None, (newest(os.path.join(p, "*", "*_counter_collection.csv")) for p in glob.glob(os.path.join(src, prefix + "_[0-9]*"))))):
@@ -48,7 +53,9 @@ def counters(prefix, sum_timed=False):
         for k, v in byc.items():
             v.sort()
             vals = [x[1] for x in v]
-            res[k] = dict(mean_timed=(float(np.sum(vals[4:24])) / 20.0 if sum_timed else float(np.mean(vals[4:24]))), launches=len(vals))
+            if len(vals) < 20:
+                continue
+            res[k] = dict(mean_timed=(float(np.sum(vals[-20:])) / 20.0 if sum_timed else float(np.mean(vals[-20:]))), launches=len(vals))
     return res
 
 
@@ -62,6 +69,12 @@ def derive(c, trace, rays=1 << 20):
         der["fetch_bytes_per_launch"] = int(2 * g("FETCH_SIZE") * 1024.0)
         der["write_bytes_per_launch"] = int(g("WRITE_SIZE") * 1024.0)
         der["write_x_compulsory"] = round(g("WRITE_SIZE") * 1024.0 / (rays * 16.0), 2)
+        if g("TCC_EA0_WRREQ_sum") is not None and g("TCC_EA0_WRREQ_64B_sum") is not None:
+            # where the write traffic beyond the 16 B records comes from: the L2 writes back in 32 B and 64 B requests; a 16 B result that
+            # leaves the L2 alone still costs a 32 B request, and a line whose records retire at different times is written back more than once
+            w64, wall = g("TCC_EA0_WRREQ_64B_sum"), g("TCC_EA0_WRREQ_sum")
+            der["write_requests"] = dict(total=wall, of_64B=w64, of_32B=wall - w64, bytes_by_request_size=int(64 * w64 + 32 * (wall - w64)),
+                                         results_per_request=round(rays / wall, 3) if wall else None)
         if der["kernel_ms_isolated"]:
             der["fabric_frac_of_hbm_peak_isolated"] = round(der["fabric_bytes_per_launch"] / (der["kernel_ms_isolated"] * 1e-3) / 8e12, 4)
     if cycles:
@@ -88,14 +101,17 @@ def derive(c, trace, rays=1 << 20):
 
 out = {}
 for sub, name in (("stats", "kernel_stats.csv"), ("stats_one_lane", "kernel_stats_one_lane.csv"), ("stats_one_lane_coherent", "kernel_stats_one_lane_coherent.csv"),
-                  ("stats_one_lane_v10", "kernel_stats_one_lane_v10.csv")):
+                  ("stats_one_lane_v10", "kernel_stats_one_lane_v10.csv"), ("stats_one_lane_xl", "kernel_stats_one_lane_xl.csv"),
+                  ("stats_one_lane_xl_diffuse", "kernel_stats_one_lane_xl_diffuse.csv")):
     s_ = newest(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
     if s_:
         shutil.copy(s_, os.path.join(dst, name))
 _, out["kernel_trace"] = trace_durations("stats")
-traces = {k: trace_durations(sub)[1] for k, sub in (("diffuse", "stats_one_lane"), ("coherent", "stats_one_lane_coherent"), ("v10_diffuse", "stats_one_lane_v10"))}
+traces = {k: trace_durations(sub)[1] for k, sub in (("diffuse", "stats_one_lane"), ("coherent", "stats_one_lane_coherent"), ("v10_diffuse", "stats_one_lane_v10"),
+                                                    ("xl", "stats_one_lane_xl"), ("xl_diffuse", "stats_one_lane_xl_diffuse"))}
 out["kernel_trace_one_lane"] = traces
-pm = {"diffuse": counters("pmc"), "coherent": counters("pmcc"), "v10_diffuse": counters("pmcv"), "diffuse_chained": counters("pmcx", sum_timed=True)}
+pm = {"diffuse": counters("pmc"), "coherent": counters("pmcc"), "v10_diffuse": counters("pmcv"), "diffuse_chained": counters("pmcx", sum_timed=True),
+      "xl": counters("pmcxl"), "xl_diffuse": counters("pmcxd")}
 out["counters"] = pm
 h = hashlib.sha256()
 for rel in ("rayaccel_amd/csrc/racc_kernel_v8.inc", "rayaccel_amd/csrc/racc_device.inc"):
@@ -122,7 +138,7 @@ der = dict(kernel_source_sha256=out["kernel_source_sha256"], kernel_v10_source_s
                l2_hit_rate="TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)",
                vmem_rd_insts_per_ray="SQ_INSTS_VMEM_RD / 2^20 rays (wave-level instructions)",
                fabric_bytes_per_step_chained="(2 * sum FETCH_SIZE + sum WRITE_SIZE) * 1024 over the traversal dispatches of the 20 timed steps / 20, three lanes, chained (rocprofv3 serialises dispatches under --pmc)"))
-for key in ("diffuse", "coherent", "v10_diffuse"):
+for key in ("diffuse", "coherent", "v10_diffuse", "xl", "xl_diffuse"):
     der[key] = derive(pm[key], traces.get(key))
 cx = pm["diffuse_chained"]
 if cx.get("FETCH_SIZE") and cx.get("WRITE_SIZE"):
