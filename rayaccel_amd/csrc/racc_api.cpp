@@ -310,7 +310,7 @@ Configuration defaultConfiguration(GpuContext gpuContext) {   // reference :429-
     cfg.allowCpuTracing = false;
     const unsigned hw = usableCpus();
     cfg.cpuThreads = std::min(hw > 2 ? hw - 2 : 1u, 32u);   // callbacks only; leave room for the submission threads
-    cfg.gpuSubmissionThreads = 2 * (gpuContext ? gpuContext->count : 1u);   // per GPU: one launch + one copy in flight
+    cfg.gpuSubmissionThreads = 4 * (gpuContext ? gpuContext->count : 1u);   // per GPU: copy-in, kernel and copy-out of consecutive launches in flight (racc_hostpath.inc; the reference's own default is 4, RayAccelerator.cpp:436)
     cfg.maxRaysInFlight = 4u << 20;                         // reference 262,144 = 29 x its iGPU's 8,960 lanes; MI355X holds 327,680+
     cfg.maxRaysPerSpawn = 128 * 128;
     cfg.cpuTestBatch = 1024;
