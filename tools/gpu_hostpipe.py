@@ -43,6 +43,14 @@ for lanes in ([int(os.environ['RACC_HOSTPIPE_LANES'])] if os.environ.get('RACC_H
             for k in range(nb): ctx.intersect(scene, env, batches[k], outs[k])
             dt = time.perf_counter() - t
             print(json.dumps(dict(blocking_sliced=True, grays=round(nb * n / dt / 1e9, 3))), flush=True)
+        if os.environ.get("RACC_HOSTPIPE_SAME"):      # bench.py's form: ONE ray array for every batch, 8 result arrays, 8 / 16 / 64 batches in a row
+            def many(m):
+                t = time.perf_counter()
+                for k in range(m):
+                    lib.racc_hip_intersect_async(ctx._h, scene._h, env._h, batches[0].ctypes.data_as(C.c_void_p), outs[k % nb].ctypes.data_as(C.c_void_p), n, k % lanes)
+                ctx.wait(ra.LANE_AUTO)
+                return round((time.perf_counter() - t) * 1e3, 3)
+            print(json.dumps(dict(lanes=lanes, same_ray_array_ms=[many(8), many(16), many(64), many(16), many(16), many(64)])), flush=True)
         for a in batches + outs:
             lib.racc_hip_unregister_host(ctx._h, a.ctypes.data)
         scene.destroy(); env.destroy()
