@@ -38,9 +38,9 @@ def test_xl_incoherent_1M_bit_exact(gpu_ctx, xl):
     assert 0.5 < (ref["triangle"] != MISS).mean() < 0.9
     assert_bit_exact(gpu_ctx.intersect(xl["scene"], xl["env"], rays), ref, "XL incoherent, host path")
     d_r = gpu_ctx.alloc(rays.nbytes); d_r.upload(rays)
-    outs = [gpu_ctx.alloc(len(rays) * 16) for _ in range(4)]
-    for k in range(8):
-        gpu_ctx.intersect_device(xl["scene"], xl["env"], d_r.ptr, outs[k % 4].ptr, len(rays), lane=ra.LANE_AUTO)
+    outs = [gpu_ctx.alloc(len(rays) * 16) for _ in range(6)]      # one result array per batch in flight (the arrays belong to the engine until the wait)
+    for o in outs:
+        gpu_ctx.intersect_device(xl["scene"], xl["env"], d_r.ptr, o.ptr, len(rays), lane=ra.LANE_AUTO)
     gpu_ctx.wait(ra.LANE_AUTO)
     for o in outs:
         assert_bit_exact(o.download(ra.RESULT_DTYPE, len(rays)), ref, "XL incoherent, chained")

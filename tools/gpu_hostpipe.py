@@ -43,6 +43,23 @@ for lanes in ([int(os.environ['RACC_HOSTPIPE_LANES'])] if os.environ.get('RACC_H
             for k in range(nb): ctx.intersect(scene, env, batches[k], outs[k])
             dt = time.perf_counter() - t
             print(json.dumps(dict(blocking_sliced=True, grays=round(nb * n / dt / 1e9, 3))), flush=True)
+        if os.environ.get("RACC_HOSTPIPE_DEBUG"):      # which step of bench.py's sequence makes its first 16-batch run take 48 ms?
+            def many2(m, tag):
+                t = time.perf_counter()
+                stamps = []
+                for k in range(m):
+                    t1 = time.perf_counter()
+                    lib.racc_hip_intersect_async(ctx._h, scene._h, env._h, batches[0].ctypes.data_as(C.c_void_p), outs[k % nb].ctypes.data_as(C.c_void_p), n, k % lanes)
+                    stamps.append(round((time.perf_counter() - t1) * 1e3, 2))
+                t1 = time.perf_counter(); ctx.wait(ra.LANE_AUTO); w = round((time.perf_counter() - t1) * 1e3, 2)
+                print(json.dumps(dict(tag=tag, batches=m, total_ms=round((time.perf_counter() - t) * 1e3, 2), enqueue_ms=stamps, wait_ms=w)), flush=True)
+            many2(8, "warm"); many2(16, "plain16")
+            for o in outs: o[:] = 0
+            many2(16, "after zeroing the result arrays")
+            for _ in range(3): ctx.intersect(scene, env, batches[0], outs[0])
+            many2(16, "after blocking sliced calls")
+            for _ in range(3): ctx.intersect(scene, env, batches[0], outs[0])
+            many2(8, "blocking, then 8"); many2(16, "then 16"); many2(64, "then 64")
         if os.environ.get("RACC_HOSTPIPE_SAME"):      # bench.py's form: ONE ray array for every batch, 8 result arrays, 8 / 16 / 64 batches in a row
             def many(m):
                 t = time.perf_counter()
