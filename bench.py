@@ -19,6 +19,7 @@ every step's results are in HBM.  Output: ONE JSON line on rank 0.
                                     # second figure with the RCCL all-gather of the hit records inside the timed region
 """
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -235,6 +236,8 @@ def main():
     drain_kernel_times()
 
     # ---- timed region: exactly K steps, barrier + device sync on both sides --------------------
+    gc.collect()
+    gc.disable()          # no collector pause inside the K steps (a full collection of this process takes tens of milliseconds)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -242,6 +245,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+    gc.enable()
     kernel_ms = drain_kernel_times()            # HIP events around each traversal kernel, on the stream it ran on
     for k in range(1, min(args.steps, len(outs))):      # every step traced the same batch: every result array must hold the same bits
         if not torch.equal(outs[k].view(torch.int32), outs[0].view(torch.int32)):
@@ -339,15 +343,22 @@ def main():
                                                   "h2d_gbs": round(n * 32 / dt / 1e9, 1), "d2h_gbs": round(n * 16 / dt / 1e9, 1)}
 
             def pipelined(batches):
+                gc.collect()      # (a generation-2 collection of this process — torch, the scene dictionaries — takes ~35 ms: not inside a timing)
                 t_ = time.perf_counter()
+                stamps = []
                 for k in range(batches):
+                    t2 = time.perf_counter()
                     ctx.intersect_async(scene, env, ray_host, host_outs[k % 8], lane=k % lanes)
+                    stamps.append(round((time.perf_counter() - t2) * 1e3, 2))
+                t2 = time.perf_counter()
                 ctx.wait(ra.LANE_AUTO)
+                if os.environ.get("RACC_BENCH_DEBUG"):
+                    print("pipelined(%d): enqueue ms %s wait %.2f total %.2f" % (batches, stamps, (time.perf_counter() - t2) * 1e3, (time.perf_counter() - t_) * 1e3), file=sys.stderr)
                 return time.perf_counter() - t_
             pipelined(8)
             for o in host_outs:
                 o[:] = 0
-            t16, t64 = pipelined(16), pipelined(64)
+            t16, t64 = min(pipelined(16) for _ in range(3)), min(pipelined(64) for _ in range(3))      # best of three: a stall of the harness (6 ms inside one hipMemcpyAsync now and then) is not the pipeline's rate
             if any(not np.array_equal(o.view(np.uint32).reshape(-1, 4), want_bits) for o in host_outs):
                 sys.exit("bench: host batches issued back to back over the lanes changed the results")
             per = (t64 - t16) / 48.0          # per batch once the pipeline is full (the 16-batch figure carries its fill and drain: one copy-in, one kernel, one copy-out)

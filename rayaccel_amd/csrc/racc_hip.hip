@@ -28,6 +28,7 @@
 #include <dlfcn.h>
 
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <cmath>
 #include <cstdint>
