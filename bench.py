@@ -225,6 +225,11 @@ def main():
     # (every rank does it: at N > 1 all GPUs enter the timed region in the same state, and the line reports rank 0's)
     # These launches run BEFORE the warm-up steps and are reported as `pre_timed_launches`: the GPU's clocks are up when the timed
     # region starts (RACC_BENCH_ISO_LAUNCHES=0 skips them — the profiling passes do, so that their last K traversal dispatches are the K steps).
+    # No collector pause inside the K steps or between the warm-up and them: a full collection of this process takes ~35 ms, during
+    # which the GPU would sit idle and drop its clocks (seen in a rocprofv3 timeline of this command).  Collected here, once, before the
+    # isolated launches; switched back on after the timed region.
+    gc.collect()
+    gc.disable()
     iso_n = int(os.environ.get("RACC_BENCH_ISO_LAUNCHES", "60"))
     iso_ms = None
     if iso_n > 0:
@@ -236,8 +241,6 @@ def main():
     drain_kernel_times()
 
     # ---- timed region: exactly K steps, barrier + device sync on both sides --------------------
-    gc.collect()
-    gc.disable()          # no collector pause inside the K steps (a full collection of this process takes tens of milliseconds)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
