@@ -173,7 +173,7 @@ def main():
     else:
         sc = synth.battlefield_synth() if full else synth.battlefield_synth(grid=args.grid, boxes=args.grid * 6, quads=args.grid * 28)
     host = ra.HostScene(sc["vertices"], sc["indices"])
-    engine_opts = dict(time_kernels=1)
+    engine_opts = dict()      # (--engine-opts '{"time_kernels":1}' adds an event pair around every traversal kernel: `timed_region.kernel_event_ms_avg`; it costs ~1 % of `value`)
     engine_opts.update(json.loads(args.engine_opts) if args.engine_opts else {})
     ctx = ra.Context(device=device, **engine_opts)
     lanes = ctx.lanes
@@ -318,65 +318,30 @@ def main():
             ctx.intersect_device(scene, env, d_prim.data_ptr(), outs[k % len(outs)].data_ptr(), len(primary), lane=ra.LANE_AUTO)
         ctx.wait(ra.LANE_AUTO); torch.cuda.synchronize()
         extras["coherent_1M"]["back_to_back_mrays_per_s"] = round(len(primary) * args.steps / (time.perf_counter() - t1) / 1e6, 1)
-        # PCIe-inclusive rate of the host-buffer entry point (never `value`)
+        # PCIe-inclusive rate of the host-buffer entry points (never `value`): pageable arrays here, in this process ...
         res_host = np.zeros(n, ra.RESULT_DTYPE)
         ctx.intersect(scene, env, bounce, res_host)
         t1 = time.perf_counter()
         for _ in range(3):
             ctx.intersect(scene, env, bounce, res_host)
         extras["host_buffers_pcie_inclusive_mrays_per_s"] = round(3 * n / (time.perf_counter() - t1) / 1e6, 1)
-        # The same with the host arrays page-locked (racc_hip_register_host, what racc::createContext does with its stream block): the
-        # copies go by DMA.  (a) one batch at a time through the blocking entry — cut into slices so that copies run beside kernels;
-        # (b) eight batches issued back to back with racc_hip_intersect_async on rotating lanes and waited for at the end — the engine
-        # keeps copy-in, kernels and copy-out of consecutive batches in flight (racc_hostpath.inc).  PCIe is full duplex: the two
-        # directions are reported separately, each against what one direction delivers alone on this box.
-        ray_host = np.ascontiguousarray(bounce)
-        host_outs = [np.zeros(n, ra.RESULT_DTYPE) for _ in range(8)]
-        tokens = [ctx.register_host(a) for a in [ray_host] + host_outs]
-        try:
-            ctx.intersect(scene, env, ray_host, host_outs[0])
-            t1 = time.perf_counter()
-            for _ in range(5):
-                ctx.intersect(scene, env, ray_host, host_outs[0])
-            dt = (time.perf_counter() - t1) / 5
-            want_bits = d_ref_bits.cpu().numpy().view(np.uint32)
-            if not np.array_equal(host_outs[0].view(np.uint32).reshape(-1, 4), want_bits):
-                sys.exit("bench: the sliced host-buffer path changed the results")
-            extras["host_buffers_page_locked"] = {"one_batch_at_a_time_mrays_per_s": round(n / dt / 1e6, 1),
-                                                  "h2d_gbs": round(n * 32 / dt / 1e9, 1), "d2h_gbs": round(n * 16 / dt / 1e9, 1)}
-
-            def pipelined(batches):
-                gc.collect()      # (a generation-2 collection of this process — torch, the scene dictionaries — takes ~35 ms: not inside a timing)
-                t_ = time.perf_counter()
-                stamps = []
-                for k in range(batches):
-                    t2 = time.perf_counter()
-                    ctx.intersect_async(scene, env, ray_host, host_outs[k % 8], lane=k % lanes)
-                    stamps.append(round((time.perf_counter() - t2) * 1e3, 2))
-                t2 = time.perf_counter()
-                ctx.wait(ra.LANE_AUTO)
-                if os.environ.get("RACC_BENCH_DEBUG"):
-                    print("pipelined(%d): enqueue ms %s wait %.2f total %.2f" % (batches, stamps, (time.perf_counter() - t2) * 1e3, (time.perf_counter() - t_) * 1e3), file=sys.stderr)
-                return time.perf_counter() - t_
-            pipelined(8)
-            for o in host_outs:
-                o[:] = 0
-            t16, t64 = min(pipelined(16) for _ in range(3)), min(pipelined(64) for _ in range(3))      # best of three: a stall of the harness (6 ms inside one hipMemcpyAsync now and then) is not the pipeline's rate
-            if any(not np.array_equal(o.view(np.uint32).reshape(-1, 4), want_bits) for o in host_outs):
-                sys.exit("bench: host batches issued back to back over the lanes changed the results")
-            per = (t64 - t16) / 48.0          # per batch once the pipeline is full (the 16-batch figure carries its fill and drain: one copy-in, one kernel, one copy-out)
-            extras["host_buffers_page_locked"]["back_to_back"] = {
-                "mrays_per_s_64_batches": round(64 * n / t64 / 1e6, 1), "mrays_per_s_16_batches": round(16 * n / t16 / 1e6, 1),
-                "steady_state_mrays_per_s": round(n / per / 1e6, 1), "lanes": lanes,
-                "h2d_gbs": round(n * 32 / per / 1e9, 1), "d2h_gbs": round(n * 16 / per / 1e9, 1),
-                "h2d_frac_of_one_direction": round(n * 32 / per / 1e9 / PCIE_GBS_PER_DIRECTION, 3), "d2h_frac_of_one_direction": round(n * 16 / per / 1e9 / PCIE_GBS_PER_DIRECTION, 3),
-                "link_gbs_per_direction": PCIE_GBS_PER_DIRECTION,
-                "how": "page-locked 1M-ray batches, racc_hip_intersect_async on rotating lanes, one racc_hip_wait at the end; h2d/d2h = per batch in steady state "
-                       "((t64 - t16) / 48); every record of the last 8 batches compared with the device-resident path's"}
-        finally:
-            ctx.wait(ra.LANE_AUTO)
-            for t in tokens:
-                ctx.unregister_host(t)
+        if not np.array_equal(res_host.view(np.uint32).reshape(-1, 4), d_ref_bits.cpu().numpy().view(np.uint32)):
+            sys.exit("bench: the host-buffer path changed the results")
+        # ... and page-locked arrays (racc_hip_register_host, what racc::createContext does with its stream block) the way a host
+        # application binds the C-ABI: tools/host_path_bench.py in a process of its own, without torch.  (torch ships its own, older HIP
+        # runtime; the engine shares it in THIS process, and the same pipeline then moves 40-47 instead of 54 GB/s into the GPU: measured
+        # both ways, tools/gpu_hostpipe.py.)  One batch at a time through the blocking entry — cut into slices so that copies run beside
+        # kernels — and batches issued back to back with racc_hip_intersect_async on rotating lanes: copy-in, kernels and copy-out of
+        # consecutive batches in flight (racc_hostpath.inc).  PCIe is full duplex: the directions are reported separately, each against
+        # what one direction delivers alone on this box.
+        if world == 1:
+            import subprocess
+            try:
+                p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_path_bench.py"), "--grid", str(args.grid), "--device", str(device),
+                                    "--link-gbs", str(PCIE_GBS_PER_DIRECTION)], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                extras["host_buffers_page_locked"] = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else {"error": (p.stderr or p.stdout)[-300:]}
+            except Exception as e:   # noqa: BLE001
+                extras["host_buffers_page_locked"] = {"error": str(e)[:200]}
 
         # Batch-size scaling of the traversal kernel (same diffuse rays, 8 sample sets): T(N) = fixed + per-ray cost.
         if world == 1 and full and args.mode == "weak":

@@ -4,6 +4,9 @@ batch k beside the copy-out of batch k-1), page-locked arrays.  Prints Grays/s a
 import ctypes as C, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+if os.environ.get('RACC_HOSTPIPE_TORCH'):
+    import torch
+    _t = torch.zeros(1 << 20, device='cuda'); torch.cuda.synchronize()
 import rayaccel_amd as ra
 from rayaccel_amd import synth
 from oracle import oracle as orc
