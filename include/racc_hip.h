@@ -81,6 +81,11 @@ typedef struct racc_hip_options {
                                   arrays belong to the engine until racc_hip_wait on its lane has returned and may be re-issued
                                   at once after that (the exact rule: racc_hip_intersect_device below).  2 => off: every launch
                                   stands alone, the lanes' launches merely overlap (same rule) */
+    uint32_t chain_min_rays;   /* only batches of at least this many rays are chained; smaller ones are launched stand-alone on their
+                                  lane (they overlap like any two lanes' launches).  A chained launch costs the host more stream
+                                  operations, and a batch that is worked off before its successor is linked breaks the chain: 27,648-ray
+                                  streams back to back run 126 Mrays/s chained, 657 stand-alone; the crossover is between 512k and 1M
+                                  rays.  0 => default (786,432); 1 => chain every batch (tests) */
 } racc_hip_options;
 
 typedef struct racc_hip_scene_info {
@@ -185,7 +190,8 @@ int racc_hip_intersect_streams_async(racc_hip_ctx* ctx, const racc_hip_scene* sc
  * (RayAccelerator.cpp:711-717).  lane = RACC_HIP_LANE_AUTO rotates over the lanes, so a single-threaded caller that issues
  * batch after batch (stream = NULL) gets that overlap without managing lanes; racc_hip_wait(ctx, RACC_HIP_LANE_AUTO) or
  * racc_hip_synchronize then waits for all of them.
- * With stream = NULL the batch must be resident and final at the call, and — racc_hip_options::chain_launches, the default —
+ * With stream = NULL the batch must be resident and final at the call, and — racc_hip_options::chain_launches, the default, for
+ * batches of at least racc_hip_options::chain_min_rays rays (786,432) —
  * launches are CHAINED: waves of the launches issued before may start on this batch at once and carry on through it, so that
  * a sequence of batches runs like one long launch (20 batches of 1M rays back to back: 0.28 instead of 0.33 ms each).  A launch
  * on a caller's stream is never chained.

@@ -160,6 +160,7 @@ struct racc_hip_ctx {
     std::mutex chainMutex;
     struct { const racc_hip_scene* scene = nullptr; const racc_hip_env* env = nullptr; const void* kernel = nullptr; uint32_t idx = 0; Lane* lane = nullptr; bool valid = false; } chainLast;
     bool chainEnabled = true;            // RACC_CHAIN=0 switches it off
+    uint32_t chainMinRays = 3u << 18;    // (786,432) smaller batches are launched stand-alone (launchTraverse); RACC_CHAIN_MIN overrides
     hipStream_t pipeIn = nullptr, pipeOut = nullptr;      // host-buffer path: ONE copy-in and ONE copy-out stream per context (racc_hostpath.inc), created on first use
     std::mutex pipeMutex;
     bool raysBypassL1 = true;            // chained kernels load rays with system-scope loads (RACC_RAY_SCOPE=0: plain loads, A/B only)
@@ -288,6 +289,8 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
         ctx->chainEnabled = ctx->opts.chain_launches != 2u;
         if (const char* c = std::getenv("RACC_CHAIN")) ctx->chainEnabled = std::atoi(c) != 0;
         if (const char* c = std::getenv("RACC_RAY_SCOPE")) ctx->raysBypassL1 = std::atoi(c) != 0;
+        if (ctx->opts.chain_min_rays) ctx->chainMinRays = ctx->opts.chain_min_rays;
+        if (const char* c = std::getenv("RACC_CHAIN_MIN")) ctx->chainMinRays = uint32_t(std::atoll(c));
         hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&ctx->chainDev), sizeof(ChainDesc) * racc_hip_ctx::kChainRing);
         if (e1 == hipSuccess) e1 = hipMemset(ctx->chainDev, 0, sizeof(ChainDesc) * racc_hip_ctx::kChainRing);
         if (e1 == hipSuccess) {      // highest priority: a publish kernel must not wait behind the persistent waves it is meant to feed

@@ -41,7 +41,7 @@ class RaccError(RuntimeError):
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("lanes", C.c_uint32), ("waves_per_simd", C.c_uint32),
                 ("kernel_variant", C.c_uint32), ("refill_min", C.c_uint32), ("leaf_min", C.c_uint32),
-                ("chunk", C.c_uint32), ("tail_active", C.c_uint32), ("regroup_period", C.c_uint32), ("thin_reps", C.c_uint32), ("inner_reps", C.c_uint32), ("coop_same_pct", C.c_uint32), ("time_kernels", C.c_uint32), ("drain_prefetch", C.c_uint32), ("leaf_step", C.c_uint32), ("wide_below", C.c_uint32), ("chain_launches", C.c_uint32)]
+                ("chunk", C.c_uint32), ("tail_active", C.c_uint32), ("regroup_period", C.c_uint32), ("thin_reps", C.c_uint32), ("inner_reps", C.c_uint32), ("coop_same_pct", C.c_uint32), ("time_kernels", C.c_uint32), ("drain_prefetch", C.c_uint32), ("leaf_step", C.c_uint32), ("wide_below", C.c_uint32), ("chain_launches", C.c_uint32), ("chain_min_rays", C.c_uint32)]
 
 
 class SceneInfo(C.Structure):
@@ -278,7 +278,7 @@ LANE_AUTO = 0xFFFFFFFF      # RACC_HIP_LANE_AUTO
 class Context:
     """≙ racc::Context for the GPU intersect path; one per (process, GPU)."""
 
-    def __init__(self, device=0, lanes=0, waves_per_simd=0, refill_min=0, leaf_min=0, chunk=0, kernel_variant=0, tail_active=0, regroup_period=0, thin_reps=0, inner_reps=0, coop_same_pct=0, time_kernels=0, drain_prefetch=0, leaf_step=0, wide_below=0, chain_launches=0):
+    def __init__(self, device=0, lanes=0, waves_per_simd=0, refill_min=0, leaf_min=0, chunk=0, kernel_variant=0, tail_active=0, regroup_period=0, thin_reps=0, inner_reps=0, coop_same_pct=0, time_kernels=0, drain_prefetch=0, leaf_step=0, wide_below=0, chain_launches=0, chain_min_rays=0):
         lib = load_library()
         o = Options()
         o.struct_size = C.sizeof(Options)
@@ -291,6 +291,7 @@ class Context:
         o.leaf_step = leaf_step
         o.wide_below = wide_below
         o.chain_launches = chain_launches
+        o.chain_min_rays = chain_min_rays
         h = C.c_void_p()
         _check(lib.racc_hip_create(device, C.byref(o), C.byref(h)))
         self._h = h

@@ -38,7 +38,10 @@ def small_host(small_scene):
 @pytest.fixture(scope="session")
 def gpu_ctx():
     import rayaccel_amd
-    ctx = rayaccel_amd.Context(device=0)     # raises (never falls back) when the extension or GPU is missing
+    # chain_min_rays=1: the suite's shared context chains EVERY device-resident batch, as rounds 2-3 did, so that the chained path keeps
+    # being exercised with batches of every size (the default chains only batches of >= 786,432 rays: racc_hip_options::chain_min_rays;
+    # tests/test_gpu_parity.py::test_chained_launches also runs the default)
+    ctx = rayaccel_amd.Context(device=0, chain_min_rays=1)     # raises (never falls back) when the extension or GPU is missing
     yield ctx
     ctx.destroy()
 

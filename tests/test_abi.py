@@ -41,7 +41,7 @@ def test_nothing_but_the_c_abi_is_exported():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(engine.Options) == 17 * 4
+    assert C.sizeof(engine.Options) == 18 * 4
     assert C.sizeof(engine.SceneInfo) == 32 and C.sizeof(engine.LaunchInfo) == 20
     assert ra.RAY_DTYPE.itemsize == 32 and ra.RESULT_DTYPE.itemsize == 16
 
@@ -88,7 +88,7 @@ def test_shipped_build_has_the_v8_kernels_only():
     assert lib.racc_hip_variant_available(1000) == 0
     experimental = b"experimental" in lib.racc_hip_version()
     assert bool(lib.racc_hip_variant_available(22)) == experimental
-    assert ra.engine.Options.__dict__ is not None and __import__("ctypes").sizeof(ra.engine.Options) == 68      # the options block is ABI: 17 words (struct_size tells older callers apart)
+    assert ra.engine.Options.__dict__ is not None and __import__("ctypes").sizeof(ra.engine.Options) == 72      # the options block is ABI: 18 words (struct_size tells older callers apart)
 
 
 def test_traversal_kernels_use_no_scratch():

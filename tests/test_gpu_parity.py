@@ -504,9 +504,11 @@ def test_chained_launches(small_scene, small_host, small):
     other = synth.battlefield_synth(grid=24, boxes=8, quads=30)
     other_host = ra.HostScene(other["vertices"], other["indices"])
     ref_other = orc.traverse(other_host.blobs(), pool[:5000], env=small_scene["env"])
-    for chain, variant in ((0, 0), (2, 0), (0, 50)):      # (variant 50: the compressed 4-wide kernel has a chained instantiation too)
+    # (chain_min_rays = 1: every batch is chained, whatever its size — the hard case; 0: the default threshold, under which this pool's
+    #  batches of <= 130k rays are plain overlapping launches; variant 50: the compressed 4-wide kernel has a chained instantiation too)
+    for chain, variant, chain_min in ((0, 0, 1), (0, 0, 0), (2, 0, 0), (0, 50, 1)):
         check = assert_same_closest_hit if variant in WIDE_VARIANTS else assert_bit_exact
-        with ra.Context(device=0, chain_launches=chain, kernel_variant=variant) as ctx:
+        with ra.Context(device=0, chain_launches=chain, kernel_variant=variant, chain_min_rays=chain_min) as ctx:
             scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)
             scene2 = ctx.upload_scene(other_host.nodes, other_host.pairs, other_host.remap)
             env = ctx.create_environment(small_scene["env"])
@@ -527,7 +529,7 @@ def test_chained_launches(small_scene, small_host, small):
                     ctx.wait(ra.LANE_AUTO)
             ctx.wait(ra.LANE_AUTO)
             for i, (d_o, off, n, want) in enumerate(issued):
-                check(d_o.download(orc.RESULT_DTYPE, n), want[off:off + n], "chain_launches=%d, kernel_variant=%d, launch %d (%d rays)" % (chain, variant, i, n))
+                check(d_o.download(orc.RESULT_DTYPE, n), want[off:off + n], "chain_launches=%d, chain_min_rays=%d, kernel_variant=%d, launch %d (%d rays)" % (chain, chain_min, variant, i, n))
                 d_o.free()
             d_pool.free(); scene.destroy(); scene2.destroy(); env.destroy()
 

@@ -24,7 +24,7 @@ other_host = ra.HostScene(other["vertices"], other["indices"])
 ref_other = orc.traverse(other_host.blobs(), pool[:5000], env=sc["env"])
 bad_rounds = 0
 for rnd in range(rounds):
-    with ra.Context(device=0) as ctx:
+    with ra.Context(device=0, chain_min_rays=1) as ctx:
         scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
         scene2 = ctx.upload_scene(other_host.nodes, other_host.pairs, other_host.remap)
         env = ctx.create_environment(sc["env"])
