@@ -217,6 +217,7 @@ extern "C" int racc_ptdev_render_file(const char* scene_bin, int device, uint32_
         }
         PT_HIP(hipMalloc(&dFrame, frameWords * 8));
         PT_HIP(hipMemset(dFrame, 0, frameWords * 8));
+        PT_HIP(hipStreamSynchronize(nullptr));      // hipMemset is asynchronous; the pipelines' streams do not wait for the null stream
         PT_HIP(hipDeviceSynchronize());
 
         hipDeviceProp_t prop;

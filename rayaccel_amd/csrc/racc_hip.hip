@@ -300,6 +300,12 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
         }
         if (e1 == hipSuccess) e1 = hipMalloc(reinterpret_cast<void**>(&ctx->chainCursors), size_t(racc_hip_ctx::kChainRing) * 64);
         if (e1 == hipSuccess) e1 = hipMemset(ctx->chainCursors, 0, size_t(racc_hip_ctx::kChainRing) * 64);
+        // Round 4: hipMemset of device memory returns before it has run (null stream), and the lanes' streams — non-blocking — do not
+        // wait for the null stream.  A context's first chained launches could therefore draw from cursor words that were zeroed UNDER
+        // them: chunks handed out twice, the second time after the batch's miss shading had run (tests/test_gpu_parity.py::
+        // test_chained_launches, launch 1 of a fresh context: a prefix of the batch left with unshaded miss records — seen in 4 of 10
+        // runs of the suite once the timing had shifted, never in isolation).  Everything the context zeroes is complete here.
+        if (e1 == hipSuccess) e1 = hipStreamSynchronize(nullptr);
         if (e1 != hipSuccess) { racc_hip_destroy(ctx); return fail(RACC_HIP_ERR_DEVICE, "chain ring", e1); }
     }
     *out = ctx;
@@ -561,7 +567,7 @@ int racc_hip_read_stats(racc_hip_ctx* ctx, uint32_t lane, uint64_t* stats8 /* [1
     Lane& l = ctx->lanes[lane];
     HIP_TRY(hipStreamSynchronize(l.stream), "hipStreamSynchronize");
     HIP_TRY(hipMemcpy(stats8, l.cursor + 8, 128, hipMemcpyDeviceToHost), "hipMemcpy stats");
-    if (reset) HIP_TRY(hipMemset(l.cursor + 8, 0, 128), "hipMemset stats");
+    if (reset) { HIP_TRY(hipMemset(l.cursor + 8, 0, 128), "hipMemset stats"); HIP_TRY(hipStreamSynchronize(nullptr), "hipStreamSynchronize(null stream)"); }
     return RACC_HIP_OK;
 }
 

@@ -27,6 +27,15 @@ def assert_bit_exact(got, ref, what=""):
         g, r = got[f][hit].view(np.uint32), ref[f][hit].view(np.uint32)
         bad = np.nonzero(g != r)[0]
         assert len(bad) == 0, "%s %s not bit-exact at %d hits, e.g. got %r want %r" % (what, f, len(bad), got[f][hit][bad[:4]], ref[f][hit][bad[:4]])
+        off = np.nonzero(~np.isclose(got[f][~hit], ref[f][~hit], rtol=1e-5, atol=1e-5))[0]
+        if len(off):        # where in the batch: a shading kernel that ran too early leaves a contiguous stretch of parked directions
+            idx = np.nonzero(~hit)[0][off]
+            unit = np.abs(got["t"][idx] ** 2 + got["u"][idx] ** 2 + got["v"][idx] ** 2 - 1.0) < 1e-3
+            chunks = np.unique(idx // 64)
+            all_miss = np.nonzero(~hit)[0]
+            in_those = np.isin(all_miss // 64, chunks)
+            what = "%s [%d miss records off, rays %d..%d, %d of them hold a unit vector (an unshaded direction); they lie in %d of %d 64-ray chunks, which hold %d miss records in all; first chunks %s]" % (
+                what, len(idx), idx[0], idx[-1], int(unit.sum()), len(chunks), (len(got) + 63) // 64, int(in_those.sum()), chunks[:12].tolist())
         np.testing.assert_allclose(got[f][~hit], ref[f][~hit], rtol=1e-5, atol=1e-5, err_msg="%s miss colour" % what)
 
 

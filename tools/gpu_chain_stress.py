@@ -32,6 +32,8 @@ for rnd in range(rounds):
         issued = []
         for k in range(300):
             n = int(rng.choice([1, 63, 64, 65, 1000, 4097, 20000, int(rng.integers(1, len(pool)))]))
+            if os.environ.get("RACC_STRESS_FIRST") and k < 2:      # a fresh context's first two launches: a long one, a short one chained behind it
+                n = (int(os.environ["RACC_STRESS_FIRST"]), 20000)[k]
             off = int(rng.integers(0, len(pool) - n + 1))
             d_o = ctx.alloc(n * 16)
             fill = np.full(n * 4, 0xABABABAB, np.uint32)      # so that "never written" is recognisable
