@@ -212,15 +212,21 @@ class HostScene:
         return dict(nodes=self.nodes, pairs=self.pairs, remap=self.remap, pair_count=self.pair_count)
 
     def device_nodes(self, order=1):
-        """The 64 B device records racc_hip_scene_upload lays the node blob out as (racc_host_scene_device_nodes; no GPU needed):
-        [N', 16] uint32 words — child refs in words 0-1, the boxes as (min, max) plane pairs in words 4-15."""
-        lib = load_library()
-        n = C.c_uint32(0)
-        args = (_ptr(self.nodes), len(self.nodes), len(self.pairs), len(self.remap), order)
-        _check(lib.racc_host_scene_device_nodes(*args, None, 0, C.byref(n)))
-        out = np.zeros((n.value, 16), np.uint32)
-        _check(lib.racc_host_scene_device_nodes(*args, _ptr(out), n.value, C.byref(n)))
-        return out
+        """The 64 B device records racc_hip_scene_upload lays the node blob out as: see device_nodes() below."""
+        return device_nodes(self.nodes, len(self.pairs), len(self.remap), order)
+
+
+def device_nodes(nodes, pair_count, remap_count, order=1):
+    """The 64 B device records racc_hip_scene_upload lays a reference-format node blob out as (racc_host_scene_device_nodes; no GPU
+    needed): [N', 16] uint32 words — child refs in words 0-1, the boxes as (min, max) plane pairs in words 4-15."""
+    lib = load_library()
+    nodes = np.ascontiguousarray(nodes)
+    n = C.c_uint32(0)
+    args = (_ptr(nodes), len(nodes), pair_count, remap_count, order)
+    _check(lib.racc_host_scene_device_nodes(*args, None, 0, C.byref(n)))
+    out = np.zeros((n.value, 16), np.uint32)
+    _check(lib.racc_host_scene_device_nodes(*args, _ptr(out), n.value, C.byref(n)))
+    return out
 
 
 class Scene:

@@ -241,3 +241,26 @@ def test_scheduler_under_thread_sanitizer(tmp_path, small_scene, cfg):
     assert p.returncode == 0 and "ThreadSanitizer" not in p.stderr, p.stdout[-500:] + p.stderr[-4000:]
     info = json.loads(p.stdout.strip().splitlines()[-1])
     assert info["raysTraced"] == info["shaded"] > 4 * 128 * 128       # primaries + two generations of bounces, none lost
+
+
+def test_device_node_order_on_degenerate_trees():
+    """The line-paired order on shapes a SAH build never makes: a 40-deep left-leaning comb (every node has ONE inner child: all lines
+    are parent + child), a single inner node, tiny meshes (6 ... 131 unconnected triangles).  Same hits as the blob, record counts within bounds."""
+    from helpers import comb_scene, make_rays
+    comb = comb_scene(40)
+    dev = ra.engine.device_nodes(comb["nodes"], len(comb["pairs"]), len(comb["remap"]), 1)
+    assert len(dev) == 40 and dev[0, 0] == (0x80000000 | 1)            # root first, its chain link behind it
+    o = np.stack([np.linspace(-20, 20, 64), np.linspace(-15, 15, 64), np.full(64, -10.0)], 1)
+    rays = make_rays(o, [[0, 0, 1]] * 64)
+    assert orc.traverse(comb, rays).tobytes() == orc.traverse(dict(comb, nodes=_device_to_reference(dev)), rays).tobytes()
+    rng = np.random.default_rng(1)
+    for tris in (6, 9, 17, 40, 131):
+        centres = np.repeat(rng.uniform(-10, 10, (tris, 3)), 3, axis=0)      # small triangles far apart: the SAH splits down to the 2-triangle leaves
+        v = np.concatenate([(centres + rng.uniform(-0.3, 0.3, (tris * 3, 3))).astype(np.float32), np.ones((tris * 3, 1), np.float32)], 1)
+        idx = np.arange(tris * 3, dtype=np.uint32).reshape(tris, 3)
+        host = ra.HostScene(v, idx)
+        for order in (0, 1):
+            dev = host.device_nodes(order)
+            assert len(host.nodes) <= len(dev) <= len(host.nodes) + 1
+            r = synth.random_rays(2000, seed=tris, extent=12.0, ymax=10.0)
+            assert orc.traverse(host.blobs(), r).tobytes() == orc.traverse(dict(host.blobs(), nodes=_device_to_reference(dev)), r).tobytes()
