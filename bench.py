@@ -296,7 +296,8 @@ def main():
                                                "bytes_gathered_per_step": int(gathered.numel() * 4),
                                                "how": "racc_hip_allgather_results (C-ABI -> ncclAllGather), one message per rank, trace and gather serialised per step"}
         comm.destroy()
-    if rank == 0 and not args.no_extras:
+    # (N > 1: no untimed extras — rank 0 would still be measuring while the other ranks tear the process group down)
+    if rank == 0 and not args.no_extras and world == 1:
         def timed_serial(rays_t, out_t, iters):
             return ctx.intersect_device_timed(scene, env, rays_t.data_ptr(), out_t.data_ptr(), rays_t.shape[0], iters)
         # one launch at a time (what round 1 reported as `value`): the launch's drain is exposed
