@@ -376,6 +376,14 @@ class Context:
         _check(load_library().racc_hip_intersect_streams(self._h, scene._h, env._h if env else None, n, pr, po, cn, lane))
         return outs
 
+    def intersect_streams_async(self, scene, env, ray_arrays, out_arrays, lane=0):
+        """Enqueue only (racc_hip_intersect_streams_async): the arrays must stay alive and untouched until wait(lane)."""
+        n = len(ray_arrays)
+        pr = (C.c_void_p * n)(*[r.ctypes.data for r in ray_arrays])
+        po = (C.c_void_p * n)(*[o.ctypes.data for o in out_arrays])
+        cn = (C.c_uint32 * n)(*[len(r) for r in ray_arrays])
+        _check(load_library().racc_hip_intersect_streams_async(self._h, scene._h, env._h if env else None, n, pr, po, cn, lane))
+
     def intersect_device(self, scene, env, d_rays, d_results, count, lane=0, stream=None):
         _check(load_library().racc_hip_intersect_device(self._h, scene._h, env._h if env else None, d_rays, d_results, count, lane, stream))
 

@@ -296,6 +296,34 @@ def test_many_streams_in_one_launch(gpu_ctx, small):
             assert_bit_exact(got, orc.traverse(small["blobs"], rays, env=small["sc"]["env"]), "stream of %d" % len(rays))
 
 
+def test_sets_of_streams_enqueued_asynchronously_on_two_lanes(gpu_ctx, small):
+    """racc_hip_intersect_streams_async: what a submission thread of racc::render would issue if it did not block — sets of ray streams
+    (ragged, one empty) on two lanes alternately, page-locked and pageable, waited for at the end; results in place per stream."""
+    b = _batches(small)
+    pool = np.ascontiguousarray(np.concatenate([b["primary"], b["diffuse"], b["random"]]))
+    ref = orc.traverse(small["blobs"], pool, env=small["sc"]["env"])
+    cuts = [0, 5000, 5001, 5001, 30000, 47777, 60000, 60064, 90000, len(pool)]
+    sets = [(0, 3), (3, 5), (5, 9)]                                  # three launches: streams [0,3), [3,5), [5,9)
+    for pinned in (False, True):
+        rays = [np.ascontiguousarray(pool[cuts[i]:cuts[i + 1]]) for i in range(len(cuts) - 1)]
+        outs = [np.zeros(len(r), ra.RESULT_DTYPE) for r in rays]
+        tokens = [gpu_ctx.register_host(a) for a in rays + outs if len(a)] if pinned else []
+        try:
+            for rep in range(3):
+                for o in outs:
+                    o[:] = 0
+                for k, (lo, hi) in enumerate(sets):
+                    gpu_ctx.intersect_streams_async(small["scene"], small["env"], rays[lo:hi], outs[lo:hi], lane=k % 2)
+                gpu_ctx.wait(0); gpu_ctx.wait(1)
+                for i, o in enumerate(outs):
+                    if len(o):
+                        assert_bit_exact(o, ref[cuts[i]:cuts[i + 1]], "async stream %d (%s)" % (i, "page-locked" if pinned else "pageable"))
+        finally:
+            gpu_ctx.wait(ra.LANE_AUTO)
+            for t in tokens:
+                gpu_ctx.unregister_host(t)
+
+
 def test_scheduling_statistics_variant(small_scene, small_host, small):
     """The debug instantiations count what the scheduler did; every ray must be loaded exactly once and every node
     visit / pair test of the oracle's count must appear as a live lane in some step."""
