@@ -21,7 +21,7 @@ pool = pool[rng.permutation(len(pool))]
 ref_pool = orc.traverse(blobs, pool, env=sc["env"], threads=8)
 bad = 0
 for rnd in range(rounds):
-    opt = dict(kernel_variant=int(rng.choice([0, 0, 0, 41, 43, 45, 46, 49, 50, 50, 50, 51, 53] + [v for v in (22, 23, 24, 17, 11, 1, 31, 34, 38) if v in ra.engine.available_variants()])), lanes=int(rng.integers(1, 5)))
+    opt = dict(kernel_variant=int(rng.choice([0, 0, 0, 41, 43, 45, 46, 49, 50, 50, 50, 51, 53] + [v for v in (22, 23, 24, 17, 11, 1, 31, 34, 38) if v in ra.engine.available_variants()])), lanes=int(rng.integers(1, 5)), chain_min_rays=int(rng.choice([0, 1, 1, 5000])))
     if rng.random() < 0.6:
         opt.update(waves_per_simd=int(rng.integers(1, 9)), refill_min=int(rng.integers(1, 65)), leaf_min=int(rng.integers(1, 65)),
                    chunk=int(rng.choice([1, 7, 32, 64, 100, 128, 1000])), tail_active=int(rng.integers(1, 70)),
@@ -32,6 +32,7 @@ for rnd in range(rounds):
         errs = []
 
         chained = bool(rng.random() < 0.4)
+        host_async = (not chained) and bool(rng.random() < 0.4)      # page-locked host batches enqueued without waiting (racc_hip_intersect_async): the pipeline across batches
 
         def check(got, off, n, rays, lane):
             v = opt["kernel_variant"]
@@ -57,8 +58,20 @@ for rnd in range(rounds):
                     ctx.intersect_device(scene, env, d_r.ptr, d_o.ptr, n, lane=ra.LANE_AUTO)
                     pending.append((d_r, d_o, n, off, rays))
                     continue
+                if host_async:
+                    out = np.zeros(n, ra.RESULT_DTYPE)
+                    toks = [ctx.register_host(rays), ctx.register_host(out)]
+                    ctx.intersect_async(scene, env, rays, out, lane=lane)
+                    pending.append((toks, out, n, off, rays))
+                    continue
                 got = ctx.intersect(scene, env, rays, lane=lane)
                 check(got, off, n, rays, lane)
+            if host_async:
+                ctx.wait(lane)
+                for toks, out, n, off, rays in pending:
+                    check(out, off, n, rays, lane)
+                    for t in toks: ctx.unregister_host(t)
+                return
             if chained:
                 ctx.wait(ra.LANE_AUTO)
                 for d_r, d_o, n, off, rays in pending:
