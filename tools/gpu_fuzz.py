@@ -59,6 +59,7 @@ for rnd in range(rounds):
                     pending.append((d_r, d_o, n, off, rays))
                     continue
                 if host_async:
+                    rays = rays.copy()          # (own memory: page-locking overlapping slices of the pool from several threads is not what is under test)
                     out = np.zeros(n, ra.RESULT_DTYPE)
                     toks = [ctx.register_host(rays), ctx.register_host(out)]
                     ctx.intersect_async(scene, env, rays, out, lane=lane)
