@@ -32,13 +32,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_MEASURED_GBS = 6290.0      # same guide: float4-copy ceiling
 RAYS_PER_BATCH = 1 << 20
+NSETS = 8                      # ray batches that rotate through the steps of a timed region (sample sets of the same primary hits)
 XL_RAY_SEED = 7
 KERNEL_NAME = "traverseKernelV8"
 L2_PEAK_GBS = 34500.0          # same guide, "L2 (per XCD)": 4 MiB x 8, ~34.5 TB/s aggregate
 PCIE_GBS_PER_DIRECTION = 56.0  # page-locked copies on the GPU boxes, one direction alone (tools/microbench/pcie.hip; 49 + 49 with both at once)
 # rocprofv3 summaries of THIS command (tools/profile_bench.sh <round>) + microbenchmark outputs: the latest round's that is committed
-PROFILE_DIR = next(os.path.join("profiles", r) for r in ("r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "derived.json")))
-KERNEL_SOURCES = ("rayaccel_amd/csrc/racc_kernel_v8.inc", "rayaccel_amd/csrc/racc_device.inc")
+PROFILE_DIR = next(os.path.join("profiles", r) for r in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "derived.json")))
+# what the committed counters depend on: the kernel, its launch policy (chunk, grid, chain), the device node order — and the tree builder
+KERNEL_SOURCES = ("rayaccel_amd/csrc/racc_kernel_v8.inc", "rayaccel_amd/csrc/racc_device.inc", "rayaccel_amd/csrc/racc_launch.inc",
+                  "rayaccel_amd/csrc/racc_scene_format.inc", "rayaccel_amd/csrc/racc_hip.hip", "rayaccel_amd/csrc/scene_build.cpp")
 CU_CLOCK_HZ, CUS = 2.4e9, 256
 
 
@@ -122,6 +125,10 @@ def main():
                          "xl / xl_diffuse: battlefield-synth-XL (25 M triangles, 1.3 GB on the device: past the Infinity Cache) with 1M incoherent rays / "
                          "its camera's 1M first-bounce diffuse rays — profiling runs of those configs")
     ap.add_argument("--grid", type=int, default=700, help="height-field resolution of battlefield-synth (700 = full)")
+    ap.add_argument("--quality", type=int, default=1, choices=(0, 1, 2),
+                    help="racc_host_build_options.quality of the scene build: 0 = the reference's builder (Bvh2.cpp restated, byte-identical to the oracle's), "
+                         "1 (default) / 2 = the same reference-format blobs with one pair per leaf and re-inserted subtrees (fewer node visits per ray); "
+                         "the line reports the quality-0 tree's figure beside it (`reference_builder_tree`)")
     ap.add_argument("--engine-opts", default="", help="JSON dict of racc_hip_options overrides (kernel A/B and profiling runs only)")
     args = ap.parse_args()
 
@@ -138,6 +145,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    if os.environ.get("RACC_BENCH_RANK_MARKERS"):      # (tests: evidence that this rank was started, written before anything can fail)
+        open(os.path.join(os.environ["RACC_BENCH_RANK_MARKERS"], "rank%d_of_%d" % (rank, world)), "w").close()
 
     import numpy as np
     import torch                      # first: the engine then shares torch's HIP runtime in this process
@@ -172,7 +181,9 @@ def main():
         sc = synth.battlefield_synth_xl() if full else synth.battlefield_synth_xl(grid=args.grid)
     else:
         sc = synth.battlefield_synth() if full else synth.battlefield_synth(grid=args.grid, boxes=args.grid * 6, quads=args.grid * 28)
-    host = ra.HostScene(sc["vertices"], sc["indices"])
+    # (N ranks share the host's cores while they set up: the BVH build of every rank takes its share, not all of them)
+    os.environ.setdefault("RACC_BUILD_THREADS", str(max(1, usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
+    host = ra.HostScene(sc["vertices"], sc["indices"], quality=args.quality)
     engine_opts = dict()      # (--engine-opts '{"time_kernels":1}' adds an event pair around every traversal kernel: `timed_region.kernel_event_ms_avg`; it costs ~1 % of `value`)
     engine_opts.update(json.loads(args.engine_opts) if args.engine_opts else {})
     ctx = ra.Context(device=device, **engine_opts)
@@ -182,14 +193,20 @@ def main():
 
     primary, _ = synth.primary_rays(sc["camera"], 1024, 1024)
     primary_hits = ctx.intersect(scene, env, primary)                       # GPU path, host buffers
+    ray_sets = None
     if args.workload == "coherent":
         bounce = primary                       # configs[1]: the timed batch is the coherent primary batch itself
         total_rays = world * len(bounce)
     elif args.workload == "xl":
-        bounce = synth.random_rays(RAYS_PER_BATCH, XL_RAY_SEED + rank)      # incoherent: origins and directions uniform over the scene
+        # incoherent: origins and directions uniform over the scene; NSETS different batches rotate through the steps
+        ray_sets = [synth.random_rays(RAYS_PER_BATCH, XL_RAY_SEED + rank + 1000 * k) for k in range(NSETS)]
+        bounce = ray_sets[0]
         total_rays = world * len(bounce)
     elif args.mode == "weak":
-        bounce = synth.diffuse_bounce_rays(sc, primary, primary_hits, RAYS_PER_BATCH, first_sample=rank)
+        # NSETS sample sets of the same primary hits rotate through the steps: no step re-traces the rays of the step before it
+        # (a caller never issues the same rays twice); rank r starts the rotation at set r
+        ray_sets = synth.diffuse_bounce_batches(sc, primary, primary_hits, RAYS_PER_BATCH, [(rank + k) % NSETS for k in range(NSETS)])
+        bounce = ray_sets[0]
         total_rays = world * len(bounce)
     else:       # strong: configs[3], 8 sample sets = one 8M-ray batch; this rank's contiguous shard of it
         whole = np.concatenate([synth.diffuse_bounce_rays(sc, primary, primary_hits, RAYS_PER_BATCH, first_sample=k) for k in range(8)])
@@ -198,8 +215,11 @@ def main():
         bounce = np.ascontiguousarray(whole[b:e])
         del whole
     n = len(bounce)
+    if ray_sets is None:
+        ray_sets = [bounce]      # configs[1]: a fixed camera's primaries ARE the same rays every frame; strong mode: one 8M-ray batch
 
-    d_rays = torch.from_numpy(bounce.view(np.float32).reshape(n, 8).copy()).cuda()
+    d_sets = [torch.from_numpy(r.view(np.float32).reshape(n, 8).copy()).cuda() for r in ray_sets]
+    d_rays = d_sets[0]
     # One result array per batch issued between two waits: chained launches (racc_hip_options::chain_launches, the default) keep a
     # batch's arrays until the wait returns.  16 MiB each: 3.1 GiB for the default 200 steps.  The ray array is read-only and shared.
     outs = [torch.zeros((n, 4), dtype=torch.float32, device="cuda") for _ in range(min(max(args.steps, args.warmup, lanes, 2), 1024))]      # (beyond 1024 steps arrays repeat: every step writes the same bits)
@@ -209,7 +229,7 @@ def main():
     def run_overlapped(steps):
         """`steps` batches, issued like a caller of the C-ABI issues them: the engine rotates the lanes."""
         for k in range(steps):
-            ctx.intersect_device(scene, env, d_rays.data_ptr(), outs[k % len(outs)].data_ptr(), n, lane=ra.LANE_AUTO)
+            ctx.intersect_device(scene, env, d_sets[k % len(d_sets)].data_ptr(), outs[k % len(outs)].data_ptr(), n, lane=ra.LANE_AUTO)
         ctx.wait(ra.LANE_AUTO)
 
     def drain_kernel_times():
@@ -250,9 +270,9 @@ def main():
     barrier()
     gc.enable()
     kernel_ms = drain_kernel_times()            # HIP events around each traversal kernel, on the stream it ran on
-    for k in range(1, min(args.steps, len(outs))):      # every step traced the same batch: every result array must hold the same bits
-        if not torch.equal(outs[k].view(torch.int32), outs[0].view(torch.int32)):
-            sys.exit("bench: step %d of the timed region produced other results than step 0" % k)
+    for k in range(len(d_sets), min(args.steps, len(outs))):      # step k traced sample set k mod NSETS: same rays, same bits (the sets themselves are held to the oracle below)
+        if not torch.equal(outs[k].view(torch.int32), outs[k % len(d_sets)].view(torch.int32)):
+            sys.exit("bench: step %d of the timed region produced other results than step %d (same rays)" % (k, k % len(d_sets)))
     per_rank, comm_ranks = [elapsed], 1
     if world > 1:
         cdev = "cuda" if backend == "nccl" else "cpu"
@@ -266,6 +286,7 @@ def main():
     value = total_rays * args.steps / elapsed / 1e6
     launch = ctx.launch_info()
     d_ref_bits = d_out.view(torch.int32).clone()      # the default kernel's records of the timed batch (the extras reuse the result arrays)
+    set_bits = [outs[k].view(torch.int32).clone() for k in range(1, min(len(d_sets), args.steps, len(outs)))]      # ... and of the other sample sets
 
     # ---- optional extras, all outside the timed region ------------------------------------------
     extras = {}
@@ -344,9 +365,38 @@ def main():
             except Exception as e:   # noqa: BLE001
                 extras["host_buffers_page_locked"] = {"error": str(e)[:200]}
 
+        # The quality-0 tree (the reference's builder, byte-identical to the oracle's restatement of Bvh2.cpp) in the SAME loop as `value`,
+        # same context, same rays, and one launch at a time: what the tree post-processing of racc_host_scene_build_ex buys.
+        if args.quality and world == 1 and args.mode == "weak" and not xl_run:
+            h0 = ra.HostScene(sc["vertices"], sc["indices"], quality=0)
+            scene0 = ctx.upload_scene(h0.nodes, h0.pairs, h0.remap)
+
+            def run0(steps):
+                for k in range(steps):
+                    ctx.intersect_device(scene0, env, d_sets[k % len(d_sets)].data_ptr(), outs[k % len(outs)].data_ptr(), n, lane=ra.LANE_AUTO)
+                ctx.wait(ra.LANE_AUTO)
+            iso0 = ctx.intersect_device_timed(scene0, env, d_rays.data_ptr(), outs[-1].data_ptr(), n, 30)
+            if args.warmup:
+                run0(args.warmup)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run0(args.steps)
+            torch.cuda.synchronize()
+            dt0 = time.perf_counter() - t1
+            same_prim = int((outs[0].view(torch.int32)[:, 0] == d_ref_bits[:, 0]).sum().item())
+            extras["reference_builder_tree"] = {
+                "mrays_per_s_same_loop_as_value": round(n * args.steps / dt0 / 1e6, 1), "ms_per_step": round(dt0 / args.steps * 1e3, 4),
+                "kernel_ms_avg_one_launch_at_a_time": round(float(np.mean(iso0[len(iso0) // 2:])), 4),
+                "inner_nodes": len(h0.nodes), "pairs": int(h0.pair_count),
+                "primIds_equal_to_the_quality_tree": "%d of %d" % (same_prim, n),
+                "what": "racc_host_build_options.quality = 0: Bvh2.cpp:257-535 restated, byte-identical to the oracle's builder; t/u/v of the two trees agree to "
+                        "rounding, primIds up to exact-distance ties (tests/test_quality_build.py, tests/test_gpu_quality.py)"}
+            scene0.destroy()
+            del h0
+
         # Batch-size scaling of the traversal kernel (same diffuse rays, 8 sample sets): T(N) = fixed + per-ray cost.
         if world == 1 and full and args.mode == "weak":
-            many = np.concatenate([bounce] + [synth.diffuse_bounce_rays(sc, primary, primary_hits, RAYS_PER_BATCH, first_sample=k) for k in range(1, 8)])
+            many = np.concatenate(ray_sets) if len(ray_sets) == 8 else np.concatenate(synth.diffuse_bounce_batches(sc, primary, primary_hits, RAYS_PER_BATCH, range(8)))
             d_many = torch.from_numpy(many.view(np.float32).reshape(len(many), 8).copy()).cuda()
             d_many_out = torch.zeros((len(many), 4), dtype=torch.float32, device="cuda")
             scaling = {}
@@ -418,7 +468,7 @@ def main():
         xl = {}
         prof_x = committed_profile() or {}
         sx = synth.battlefield_synth_xl()
-        hx = ra.HostScene(sx["vertices"], sx["indices"])
+        hx = ra.HostScene(sx["vertices"], sx["indices"], quality=args.quality)
         scene_x = ctx.upload_scene(hx.nodes, hx.pairs, hx.remap)
         env_x = ctx.create_environment(sx["env"])
         hits_x = ctx.intersect(scene_x, env_x, primary)
@@ -432,7 +482,7 @@ def main():
             alg_x, src_x = None, None
             if not args.no_cpu_baseline:
                 from oracle import oracle            # checker only
-                ref_x, nv_x, np_x, _ = oracle.traverse(hx.blobs(), rays_x, env=sx["env"], counters=True)
+                ref_x, nv_x, np_x, _ = oracle.traverse(hx.blobs(), rays_x, env=sx["env"], counters=True, threads=usable_cores())
                 alg_x, src_x = oracle.algorithmic_bytes(ref_x, nv_x, np_x), "oracle counters, live"
                 got_x = d_ox.cpu().numpy().view(ra.RESULT_DTYPE).reshape(-1)
                 hit_x = ref_x["triangle"] != 0xFFFFFFFF
@@ -442,7 +492,8 @@ def main():
             else:
                 try:
                     with open(os.path.join(ROOT, "tests", "golden", "algorithmic_bytes.json")) as f:
-                        alg_x, src_x = json.load(f)[key + "_1M"]["bytes"], "tests/golden/algorithmic_bytes.json"
+                        gx = json.load(f)
+                        alg_x, src_x = (gx["quality%d" % args.quality] if args.quality else gx)[key + "_1M"]["bytes"], "tests/golden/algorithmic_bytes.json"
                 except (OSError, KeyError, ValueError):
                     pass
             px = prof_x.get(key, {})
@@ -468,11 +519,23 @@ def main():
         except (OSError, ValueError):
             pass
         golden_key = {"diffuse": "diffuse_1M_sample0", "coherent": "coherent_1M", "xl": "xl_1M", "xl_diffuse": "xl_diffuse_1M"}[args.workload]
+        if args.quality:
+            golden = golden.get("quality%d" % args.quality, {})
+        alg_by_set = None
         if not args.no_cpu_baseline and world == 1 and args.mode == "weak":       # the CPU legs run at N=1 only
             from oracle import oracle            # checker / CPU leg only; never on the product path
             blobs = host.blobs()
-            ref, nv, npairs, _ = oracle.traverse(blobs, bounce, env=sc["env"], counters=True)
-            alg_bytes, src = oracle.algorithmic_bytes(ref, nv, npairs), "oracle counters, live"
+            ref, nv, npairs, _ = oracle.traverse(blobs, bounce, env=sc["env"], counters=True, threads=usable_cores())
+            alg_bytes, src = oracle.algorithmic_bytes(ref, nv, npairs), "oracle counters, live, on the blobs the GPU traverses (racc_host_build_options.quality = %d)" % args.quality
+            alg_by_set = [alg_bytes]
+            for k, bits in enumerate(set_bits, 1):      # the other sample sets of the rotation: every record against the oracle as well
+                ref_k, nv_k, np_k, _ = oracle.traverse(blobs, ray_sets[k], env=sc["env"], counters=True, threads=usable_cores())
+                got_k = bits.cpu().numpy().view(ra.RESULT_DTYPE).reshape(-1)
+                hit_k = ref_k["triangle"] != 0xFFFFFFFF
+                if not np.array_equal(got_k["triangle"], ref_k["triangle"]) or any(
+                        not np.array_equal(got_k[f][hit_k].view(np.uint32), ref_k[f][hit_k].view(np.uint32)) for f in ("t", "u", "v")):
+                    sys.exit("bench: GPU results of sample set %d differ from the oracle — refusing to report a number" % k)
+                alg_by_set.append(oracle.algorithmic_bytes(ref_k, nv_k, np_k))
             got = d_ref_bits.cpu().numpy().view(ra.RESULT_DTYPE).reshape(-1)
             hit = ref["triangle"] != 0xFFFFFFFF
             if not np.array_equal(got["triangle"], ref["triangle"]) or any(
@@ -525,6 +588,7 @@ def main():
         traffic = pw.get("fabric_bytes_per_launch")
         step_s = elapsed / args.steps
         ceiling = gather_ceiling()
+        alg_step = float(np.mean(alg_by_set)) if alg_by_set else alg_bytes      # the timed steps rotate through the sample sets
         if iso_ms:
             # The contract's roofline: `achieved` = the ALGORITHMIC bytes of SURVEY §8(d) per launch (every node / pair the reference's
             # traversal order touches, counted by the oracle) over the traversal kernel's launch duration (HIP events, the kernel alone
@@ -548,11 +612,11 @@ def main():
                 "bound_actual": None if not alg_bytes else {
                     "what": "the algorithmic bytes against the levels they pass through on this scene (cache-resident: L2 hit rate %s)" % pw.get("l2_hit_rate", "n/a"),
                     "l2_aggregate": {"peak_gbs": L2_PEAK_GBS, "frac_isolated_launch": round(alg_bytes / (iso_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4),
-                                     "frac_timed_region": round(alg_bytes / step_s / 1e9 / L2_PEAK_GBS, 4)},
+                                     "frac_timed_region": round(alg_step / step_s / 1e9 / L2_PEAK_GBS, 4)},
                     "cu_gather_path": None if not ceiling else {
                         "measured_ceiling_B_per_clk_per_CU": ceiling,
                         "frac_isolated_launch": round(alg_bytes / (iso_ms * 1e-3) / (CUS * CU_CLOCK_HZ) / ceiling, 4),
-                        "frac_timed_region": round(alg_bytes / step_s / (CUS * CU_CLOCK_HZ) / ceiling, 4),
+                        "frac_timed_region": round(alg_step / step_s / (CUS * CU_CLOCK_HZ) / ceiling, 4),
                         "frac_steady_state": (round(alg_bytes / ((1 << 20) / (extras["batch_scaling"]["steady_state_mrays_per_s"] * 1e6)) / (CUS * CU_CLOCK_HZ) / ceiling, 4)
                                               if "batch_scaling" in extras else None),
                         "note": "256 CUs x 2.4 GHz; ceiling = tools/microbench/gather64.hip mode 2 (64 random 64 B records per wave through quad-cooperative LDS-DMA, "
@@ -563,14 +627,15 @@ def main():
                                 "the kernel alone on the GPU as for `achieved`; includes Infinity-Cache hits, so an upper bound of HBM traffic; %s/pmc_summary.json" % PROFILE_DIR,
                 # the timed region: launches are chained and overlap, so the rate is bytes per launch over the time the region spends per launch
                 "timed_region": None if not alg_bytes else {
-                    "ms_per_step": round(step_s * 1e3, 4), "algorithmic_gbs": round(alg_bytes / step_s / 1e9, 1),
-                    "x_hbm_peak": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "ms_per_step": round(step_s * 1e3, 4), "algorithmic_gbs": round(alg_step / step_s / 1e9, 1),
+                    "x_hbm_peak": round(alg_step / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "ray_batches_in_rotation": len(d_sets), "algorithmic_bytes_per_step_mean": int(alg_step),
                     "kernel_event_ms_avg": round(avg_kernel_ms, 4) if avg_kernel_ms else None,
                     "kernel_event_note": "HIP events around every traversal kernel of the timed region: chained launches — the first kernels of a sequence work "
                                          "through the later batches, whose own kernels then find nothing left — so this is not a per-launch duration",
                     "fabric_bytes_per_step_chained": pw.get("fabric_bytes_per_step_chained")},
                 "limiter": None if not pw else {k: pw.get(k) for k in (
-                    "bound", "td_busy_frac", "ta_busy_frac", "valu_busy_frac", "issue_slot_frac", "valu_lane_util", "salu_share",
+                    "bound", "td_busy_frac", "ta_busy_frac", "valu_busy_frac", "valu_lane_util", "salu_share",
                     "l2_hit_rate", "vmem_rd_insts_per_ray", "valu_insts_per_ray", "kernel_ms_isolated", "write_x_compulsory")},
                 "profile_source": (prof or {}).get("source"),
                 "profile_stale": bool(prof["stale"]) if prof else None})
@@ -608,6 +673,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_text,
                        "rays_per_gpu": n, "scene": sc["name"], "parallelism": "rays sharded x%d, scene replicated" % world,
+                       "tree": ("racc_host_build_options.quality = %d: %d inner nodes, %d pairs (reference format; " % (args.quality, len(host.nodes), host.pair_count)) +
+                               ("the reference's builder, Bvh2.cpp restated)" if args.quality == 0 else "one pair per leaf + re-inserted subtrees; `reference_builder_tree` = the quality-0 tree in the same loop)"),
+                       "ray_batches_in_rotation": len(d_sets),
                        "grid_blocks": launch["grid_blocks"], "waves_per_simd": launch["waves_per_simd"], "lanes": lanes,
                        "lanes_in_rotation": ctx.auto_lanes, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             "roofline": roofline, "cpu_baseline": cpu_baseline,

@@ -130,7 +130,17 @@ def traverse(scene, rays, env=None, counters=False, threads=1, repeat=1, out=Non
     nodes, pairs, remap = scene["nodes"], scene["pairs"], scene["remap"]
     if counters:
         nv, npp, dp = (np.zeros(n, np.uint32) for _ in range(3))
-        lib().orc_traverse(_p(nodes), _p(pairs), _p(remap), envp, w, h, _p(rays), _p(out), 0, n, _p(nv), _p(npp), _p(dp))
+        if threads > 1 and n >= 4096:
+            # orc_traverse takes a ray range and ctypes releases the GIL: slices on Python threads (per-ray counters, so no sharing)
+            import threading
+            L = lib()
+            cuts = [n * k // threads for k in range(threads + 1)]
+            ts = [threading.Thread(target=L.orc_traverse, args=(_p(nodes), _p(pairs), _p(remap), envp, w, h, _p(rays), _p(out), cuts[k], cuts[k + 1], _p(nv), _p(npp), _p(dp)))
+                  for k in range(threads)]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+        else:
+            lib().orc_traverse(_p(nodes), _p(pairs), _p(remap), envp, w, h, _p(rays), _p(out), 0, n, _p(nv), _p(npp), _p(dp))
         return out, nv, npp, dp
     if threads > 1 or repeat > 1:
         lib().orc_traverse_mt(_p(nodes), _p(pairs), _p(remap), envp, w, h, _p(rays), _p(out), n, 1024, threads, repeat)

@@ -110,6 +110,7 @@ ABI = {
     "racc_hip_allgather_results": (_i, [_vp, _vp, _vp, _u32, _vp]),
     "racc_hip_comm_destroy": (_i, [_vp]),
     "racc_host_scene_build": (_i, [_vp, _u32, _vp, _u32, _P(_vp)]),
+    "racc_host_scene_build_ex": (_i, [_vp, _u32, _vp, _u32, _vp, _P(_vp)]),
     "racc_host_scene_free": (_i, [_vp]),
     "racc_host_scene_blobs": (_i, [_vp, _P(_vp), _P(_u32), _P(_vp), _P(_u32), _P(_u32), _P(_vp), _P(_u32)]),
     "racc_host_scene_bvh2": (_i, [_vp, _P(_vp), _P(_u32), _P(_vp), _P(_u32)]),
@@ -183,15 +184,26 @@ def device_count():
     return n.value if rc == 0 else 0
 
 
-class HostScene:
-    """Host-side build product ≙ the GPU branch of racc::createScene (Scene.cpp:216-339)."""
+class HostBuildOptions(C.Structure):
+    """racc_host_build_options (include/racc_hip.h)."""
+    _fields_ = [("struct_size", _u32), ("quality", _u32), ("threads", _u32), ("reserved", _u32 * 5)]
 
-    def __init__(self, vertices, indices):
+
+class HostScene:
+    """Host-side build product ≙ the GPU branch of racc::createScene (Scene.cpp:216-339).  quality 0 = the reference's builder
+    (byte-identical to the oracle's restatement); 1 / 2 = the same format with fewer node visits per ray (racc_host_scene_build_ex)."""
+
+    def __init__(self, vertices, indices, quality=0, threads=0):
         lib = load_library()
         v = _as_verts4(vertices)
         idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
         h = C.c_void_p()
-        _check(lib.racc_host_scene_build(_ptr(v), len(v), _ptr(idx), idx.size, C.byref(h)))
+        self.quality = int(quality)
+        if quality or threads:
+            opt = HostBuildOptions(struct_size=C.sizeof(HostBuildOptions), quality=int(quality), threads=int(threads))
+            _check(lib.racc_host_scene_build_ex(_ptr(v), len(v), _ptr(idx), idx.size, C.byref(opt), C.byref(h)))
+        else:
+            _check(lib.racc_host_scene_build(_ptr(v), len(v), _ptr(idx), idx.size, C.byref(h)))
         try:
             pn, pp, pr = C.c_void_p(), C.c_void_p(), C.c_void_p()
             nn, npad, npair, nr = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()

@@ -242,6 +242,12 @@ def diffuse_bounce_rays(scene, rays, results, count, seed=DIFFUSE_SEED, first_sa
     maxT=1e6.  Misses are skipped; the hit list is re-cycled with the next
     sample index until exactly `count` rays exist.  Order = primary order, i.e.
     spatially coherent origins with incoherent directions."""
+    return diffuse_bounce_batches(scene, rays, results, count, [first_sample], seed)[0]
+
+
+def diffuse_bounce_batches(scene, rays, results, count, first_samples, seed=DIFFUSE_SEED):
+    """Several diffuse_bounce_rays batches (one per entry of `first_samples`) off the same primary hits: the hit points and
+    tangent frames are computed once."""
     hit = np.nonzero(results["triangle"] != INVALID_TRIANGLE)[0]
     if len(hit) == 0:
         raise ValueError("no primary hits to bounce from")
@@ -257,25 +263,29 @@ def diffuse_bounce_rays(scene, rays, results, count, seed=DIFFUSE_SEED, first_sa
     bu = np.cross(helper, ng)
     bu /= np.linalg.norm(bu, axis=1, keepdims=True)
     bv = np.cross(ng, bu)
+    origin32 = (P + 1e-4 * ng).astype(np.float32)
 
-    out = np.zeros(count, RAY_DTYPE)
-    filled, sample = 0, first_sample
-    while filled < count:
-        n = min(len(hit), count - filled)
-        ctr = hit[:n].astype(np.uint64) + np.uint64(sample) * np.uint64(0x01000193)
-        r1 = hash_uniform(ctr, 41, seed)[:n].astype(np.float64) * 2 * np.pi
-        r2 = hash_uniform(ctr, 42, seed)[:n].astype(np.float64)
-        s = np.sqrt(r2)
-        d = ng[:n] * np.sqrt(1 - r2)[:, None] + (bu[:n] * np.cos(r1)[:, None] + bv[:n] * np.sin(r1)[:, None]) * s[:, None]
-        d = _normalize(d)
-        sl = slice(filled, filled + n)
-        out["origin"][sl] = (P[:n] + 1e-4 * ng[:n]).astype(np.float32)
-        out["minT"][sl] = 1e-3
-        out["dir"][sl] = d.astype(np.float32)
-        out["maxT"][sl] = 1e6
-        filled += n
-        sample += 1
-    return out
+    batches = []
+    for first_sample in first_samples:
+        out = np.zeros(count, RAY_DTYPE)
+        filled, sample = 0, first_sample
+        while filled < count:
+            n = min(len(hit), count - filled)
+            ctr = hit[:n].astype(np.uint64) + np.uint64(sample) * np.uint64(0x01000193)
+            r1 = hash_uniform(ctr, 41, seed)[:n].astype(np.float64) * 2 * np.pi
+            r2 = hash_uniform(ctr, 42, seed)[:n].astype(np.float64)
+            s = np.sqrt(r2)
+            d = ng[:n] * np.sqrt(1 - r2)[:, None] + (bu[:n] * np.cos(r1)[:, None] + bv[:n] * np.sin(r1)[:, None]) * s[:, None]
+            d = _normalize(d)
+            sl = slice(filled, filled + n)
+            out["origin"][sl] = origin32[:n]
+            out["minT"][sl] = 1e-3
+            out["dir"][sl] = d.astype(np.float32)
+            out["maxT"][sl] = 1e6
+            filled += n
+            sample += 1
+        batches.append(out)
+    return batches
 
 
 def random_rays(count, seed, extent=100.0, ymax=40.0):

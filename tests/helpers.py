@@ -82,7 +82,7 @@ def assert_same_closest_hit(got, ref, what="", max_ties=None, arbiter=None):
     return len(bad)
 
 
-def assert_matches_arbiter(res, scene, rays, rel=1e-4):
+def assert_matches_arbiter(res, scene, rays, rel=1e-4, uv_atol=2e-5):
     """SURVEY.md §8(c) acceptance rule against the double-precision brute force (north_star: primId
     exact, t/u/v within 1e-4 rel).  On a tie (two triangles within 1e-6 rel in t) either id is accepted
     provided re-intersecting the REPORTED triangle in double reproduces the reported t,u,v."""
@@ -100,8 +100,8 @@ def assert_matches_arbiter(res, scene, rays, rel=1e-4):
     both = hit_g & hit_b
     same = both & (res["triangle"] == tri)
     np.testing.assert_allclose(res["t"][same], t[same], rtol=rel, atol=0)
-    np.testing.assert_allclose(res["u"][same], u[same], rtol=rel, atol=2e-5)
-    np.testing.assert_allclose(res["v"][same], vv[same], rtol=rel, atol=2e-5)
+    np.testing.assert_allclose(res["u"][same], u[same], rtol=rel, atol=uv_atol)
+    np.testing.assert_allclose(res["v"][same], vv[same], rtol=rel, atol=uv_atol)
     for i in np.nonzero(both & ~same)[0]:
         ok, tt, uu, v2 = orc.brute_one(v, idx, res["triangle"][i], rays[i])
         assert ok, "ray %d: reported tri %d is not hit at all in double precision (arbiter: tri %d)" % (i, res["triangle"][i], tri[i])

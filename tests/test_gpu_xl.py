@@ -66,3 +66,36 @@ def test_xl_against_the_reference_kernel(gpu_ctx, xl):
     reference = ref_kernel.run(xl["blobs"], rays, xl["sc"]["env"])
     _compare(reference, orc.traverse(xl["blobs"], rays, threads=16), "oracle vs reference kernel, XL")
     _compare(reference, gpu_ctx.intersect(xl["scene"], None, rays), "HIP engine vs reference kernel, XL")
+
+
+def test_xl_quality_tree_bit_exact(gpu_ctx, xl):
+    """The same 25 M triangles through racc_host_scene_build_ex(quality = 1) — 13 M one-pair leaves, subtrees re-inserted; what bench.py's
+    XL rows run on: the incoherent 1M batch, host path and chained, every record against the oracle on the same blobs; and against the
+    reference builder's tree (same hits) with the visit counts that are the point of the mode."""
+    sc = xl["sc"]
+    host = ra.HostScene(sc["vertices"], sc["indices"], quality=1)
+    scene = gpu_ctx.upload_scene(host.nodes, host.pairs, host.remap)
+    try:
+        assert scene.info["pair_count"] < (1 << 24)
+        rays = synth.random_rays(1 << 20, 7)
+        ref, nv, npairs, _ = orc.traverse(host.blobs(), rays, env=sc["env"], counters=True, threads=16)
+        got = gpu_ctx.intersect(scene, xl["env"], rays)
+        assert_bit_exact(got, ref, "XL incoherent, quality 1, host path")
+        d_r = gpu_ctx.alloc(rays.nbytes); d_r.upload(rays)
+        outs = [gpu_ctx.alloc(len(rays) * 16) for _ in range(4)]
+        for o in outs:
+            gpu_ctx.intersect_device(scene, xl["env"], d_r.ptr, o.ptr, len(rays), lane=ra.LANE_AUTO)
+        gpu_ctx.wait(ra.LANE_AUTO)
+        for o in outs:
+            assert_bit_exact(o.download(ra.RESULT_DTYPE, len(rays)), ref, "XL incoherent, quality 1, chained")
+            o.free()
+        d_r.free()
+        base, nv0, np0, _ = orc.traverse(xl["blobs"], rays, env=sc["env"], counters=True, threads=16)
+        assert ((base["triangle"] == MISS) != (ref["triangle"] == MISS)).sum() <= 8
+        both = (base["triangle"] != MISS) & (ref["triangle"] != MISS)
+        other = both & (base["triangle"] != ref["triangle"])
+        assert other.sum() <= 32 and np.allclose(base["t"][other], ref["t"][other], rtol=1e-6, atol=0)
+        np.testing.assert_allclose(ref["t"][both & ~other], base["t"][both & ~other], rtol=1e-4, atol=0)
+        assert nv.mean() < 0.9 * nv0.mean() and npairs.mean() < 0.7 * np0.mean(), (nv.mean(), nv0.mean(), npairs.mean(), np0.mean())
+    finally:
+        scene.destroy()

@@ -1,4 +1,4 @@
-"""The committed rocprofv3 summaries must describe the kernel that is in the tree: profiles/r03/derived.json records the
+"""The committed rocprofv3 summaries must describe the kernel that is in the tree: profiles/<round>/derived.json records the
 hash of the kernel sources it was taken with (tools/summarize_profile.py); bench.py reports numbers from it."""
 import json
 import os
@@ -12,12 +12,12 @@ def test_committed_profile_matches_the_kernel_sources():
     import bench
     prof = bench.committed_profile()
     assert prof is not None, "no %s/derived.json: run tools/profile_bench.sh + tools/summarize_profile.py" % bench.PROFILE_DIR
-    assert not prof["stale"], "kernel sources changed after %s was taken: re-profile (tools/profile_bench.sh r03)" % bench.PROFILE_DIR
+    assert not prof["stale"], "kernel sources changed after %s was taken: re-profile (tools/profile_bench.sh <round>)" % bench.PROFILE_DIR
     for wl in ("diffuse", "coherent"):        # configs[2] (the headline) and configs[1], each from its own isolated passes
         d = prof[wl]
-        for key in ("fabric_bytes_per_launch", "td_busy_frac", "valu_busy_frac", "issue_slot_frac", "valu_lane_util", "salu_share", "kernel_ms_isolated"):
+        for key in ("fabric_bytes_per_launch", "td_busy_frac", "valu_busy_frac", "valu_lane_util", "salu_share", "kernel_ms_isolated"):
             assert d.get(key) is not None and d[key] > 0, (wl, key)
-        assert d["fabric_frac_of_hbm_peak_isolated"] < 1 and d["td_busy_frac"] <= 1 and d["issue_slot_frac"] <= 1.01
+        assert d["fabric_frac_of_hbm_peak_isolated"] < 1 and d["td_busy_frac"] <= 1 and d["valu_busy_frac"] <= 1
     assert bench.gather_ceiling() and 20 < bench.gather_ceiling() < 64          # measured, committed: profiles/<round>/microbench.json + gather64.txt
     assert os.path.exists(os.path.join(ROOT, bench.PROFILE_DIR, "gather64.txt"))
     stats = open(os.path.join(ROOT, bench.PROFILE_DIR, "kernel_stats.csv")).read()

@@ -1,0 +1,216 @@
+"""CPU tests of the optional quality mode of the host scene build (racc_host_scene_build_ex, quality 1 / 2;
+rayaccel_amd/csrc/scene_build.cpp: LeafSplitter + TreeOptimizer).  The reference has no such mode, so there is nothing to
+restate: what is checked is that the blobs are a valid reference-format scene over the same triangles (Scene.cpp:73-87,
+237-339), that the oracle's traversal of them (Kernels.h:139-242) finds what the arbiter finds and what it finds in the
+reference builder's tree, that they are deterministic for any thread count — and that they do what they are for (fewer node
+visits and pair tests per ray)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import rayaccel_amd as ra
+from oracle import oracle as orc
+from rayaccel_amd import synth
+from helpers import MISS, assert_matches_arbiter
+
+
+def _geometry_boxes(sc):
+    v = sc["vertices"][:, :3]
+    tri = v[sc["indices"].reshape(-1, 3)]
+    return tri.min(1), tri.max(1)
+
+
+def check_tree(hs, sc, one_pair_leaves):
+    """Structural validity of a reference-format blob set against the mesh it was built from."""
+    T = len(sc["indices"].reshape(-1, 3))
+    nodes, remap = hs.nodes, hs.remap
+    assert (len(hs.pairs) * 3) % 32 == 0 and len(hs.pairs) > hs.pair_count              # Scene.cpp:334-338
+    ids = remap & 0x3FFFFFFF
+    second_real = (remap[1::2] >> 30) != 0
+    used = np.concatenate([ids[0::2], ids[1::2][second_real]])
+    assert np.array_equal(np.sort(used), np.arange(T)), "every triangle exactly once"
+    kids = np.stack([nodes["first"], nodes["last"]], 1)
+    inner = kids & 0x80000000 != 0
+    refs = kids[inner] & 0x7FFFFFFF
+    assert np.array_equal(np.sort(refs), np.arange(1, len(nodes))), "every inner node but the root has exactly one parent"
+    parent_of = np.zeros(len(nodes), np.int64)
+    parent_of[kids[:, 0][inner[:, 0]] & 0x7FFFFFFF] = np.nonzero(inner[:, 0])[0]
+    parent_of[kids[:, 1][inner[:, 1]] & 0x7FFFFFFF] = np.nonzero(inner[:, 1])[0]
+    assert (parent_of[1:] < np.arange(1, len(nodes))).all(), "parents are numbered before their children (depth-first numbering)"
+    leaves = kids[~inner]
+    first, cnt = leaves & 0xFFFFFF, leaves >> 24
+    order = np.argsort(first)
+    assert cnt.min() >= 1 and cnt.max() <= 127
+    assert np.array_equal(first[order][1:], (first + cnt)[order][:-1]) and (first + cnt).max() == hs.pair_count
+    if one_pair_leaves:
+        assert cnt.max() == 1, "quality builds hold one pair per leaf"
+    # boxes: a child box is exactly the union of the triangles below it (bottom-up over the depth-first numbering)
+    tlo, thi = _geometry_boxes(sc)
+    plo = np.full((hs.pair_count, 3), np.inf, np.float32)
+    phi = np.full((hs.pair_count, 3), -np.inf, np.float32)
+    a = ids[0:2 * hs.pair_count:2]
+    plo, phi = np.minimum(plo, tlo[a]), np.maximum(phi, thi[a])
+    b = ids[1:2 * hs.pair_count:2]
+    sr = second_real[:hs.pair_count]
+    plo[sr], phi[sr] = np.minimum(plo[sr], tlo[b[sr]]), np.maximum(phi[sr], thi[b[sr]])
+    nlo = np.zeros((len(nodes), 3), np.float32)
+    nhi = np.zeros((len(nodes), 3), np.float32)
+    for i in range(len(nodes) - 1, -1, -1):
+        lo2, hi2 = [], []
+        for side, (bmin, bmax) in enumerate((("leftMin", "leftMax"), ("rightMin", "rightMax"))):
+            ref = int(kids[i, side])
+            if ref & 0x80000000:
+                lo, hi = nlo[ref & 0x7FFFFFFF], nhi[ref & 0x7FFFFFFF]
+            else:
+                f, c = ref & 0xFFFFFF, ref >> 24
+                lo, hi = plo[f:f + c].min(0), phi[f:f + c].max(0)
+            assert np.array_equal(nodes[bmin][i], lo) and np.array_equal(nodes[bmax][i], hi), "node %d side %d: box is not the union of its triangles" % (i, side)
+            lo2.append(lo); hi2.append(hi)
+        nlo[i], nhi[i] = np.minimum(lo2[0], lo2[1]), np.maximum(hi2[0], hi2[1])
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return synth.battlefield_synth(grid=64, boxes=120, quads=700)        # 11k triangles: a dozen subtrees of the first phase
+
+
+@pytest.fixture(scope="module")
+def batches(scene):
+    prim, _ = synth.primary_rays(scene["camera"], 128, 128)
+    base = orc.build_scene(scene["vertices"], scene["indices"])
+    ref = orc.traverse(base, prim)
+    diff = synth.diffuse_bounce_rays(scene, prim, ref, 16384)
+    rnd = synth.random_rays(8192, 7, extent=100.0, ymax=30.0)
+    return dict(primary=prim, diffuse=diff, random=rnd, base=base)
+
+
+def test_quality_zero_through_the_options_entry_is_the_reference_build(scene):
+    a = ra.HostScene(scene["vertices"], scene["indices"])
+    b = ra.HostScene(scene["vertices"], scene["indices"], quality=0, threads=3)
+    assert a.nodes.tobytes() == b.nodes.tobytes() and a.pairs.tobytes() == b.pairs.tobytes() and a.remap.tobytes() == b.remap.tobytes()
+
+
+@pytest.mark.parametrize("quality", [1, 2])
+def test_quality_blobs_are_a_valid_scene(scene, quality):
+    hs = ra.HostScene(scene["vertices"], scene["indices"], quality=quality)
+    check_tree(hs, scene, one_pair_leaves=True)
+
+
+def test_reference_build_passes_the_same_validity_check(scene):
+    check_tree(ra.HostScene(scene["vertices"], scene["indices"]), scene, one_pair_leaves=False)
+
+
+@pytest.mark.parametrize("quality", [1, 2])
+def test_quality_build_is_identical_for_any_thread_count(quality):
+    sc = synth.battlefield_synth(grid=96, boxes=300, quads=1500)          # ~26k triangles: ~25 subtrees of <= 1024 leaves
+    blobs = [ra.HostScene(sc["vertices"], sc["indices"], quality=quality, threads=t) for t in (1, 3, 8)]
+    for b in blobs[1:]:
+        assert b.nodes.tobytes() == blobs[0].nodes.tobytes() and b.pairs.tobytes() == blobs[0].pairs.tobytes() and b.remap.tobytes() == blobs[0].remap.tobytes()
+
+
+@pytest.mark.parametrize("quality", [1, 2])
+def test_quality_tree_finds_what_the_arbiter_finds(scene, batches, quality):
+    hs = ra.HostScene(scene["vertices"], scene["indices"], quality=quality)
+    for name in ("primary", "diffuse", "random"):
+        rays = batches[name][:4096]
+        res = orc.traverse(hs.blobs(), rays)
+        # (u/v of one grazing first-bounce ray of this batch are 3.6e-5 off the double-precision values in binary32 — in the
+        #  reference builder's tree just the same: the pair test's rounding, not the tree's doing)
+        assert_matches_arbiter(res, scene, rays, uv_atol=1e-4)
+
+
+@pytest.mark.parametrize("quality", [1, 2])
+def test_quality_tree_against_the_reference_builders_tree(scene, batches, quality):
+    """Same triangles, same pair test, another tree: the closest hit is the same triangle (or another one at the same
+    distance), t/u/v agree to rounding — a triangle may sit in another pair, or at another corner of its pair (north_star:
+    primId exact, t/u/v within 1e-4 relative)."""
+    hs = ra.HostScene(scene["vertices"], scene["indices"], quality=quality)
+    ties = 0
+    for name in ("primary", "diffuse", "random"):
+        rays = batches[name]
+        a = orc.traverse(batches["base"], rays)
+        b = orc.traverse(hs.blobs(), rays)
+        # hit/miss may differ only for rays that graze an edge within rounding (each tree's pair test sees its own rounding)
+        dis = np.nonzero((a["triangle"] == MISS) != (b["triangle"] == MISS))[0]
+        assert len(dis) <= max(2, len(rays) // 20000), "%s: %d hit/miss differences" % (name, len(dis))
+        both = (a["triangle"] != MISS) & (b["triangle"] != MISS)
+        other = both & (a["triangle"] != b["triangle"])
+        assert np.allclose(a["t"][other], b["t"][other], rtol=1e-6, atol=0), "another triangle is only acceptable at the same distance"
+        ties += int(other.sum())
+        same = both & ~other
+        np.testing.assert_allclose(b["t"][same], a["t"][same], rtol=1e-4, atol=0)
+        np.testing.assert_allclose(b["u"][same], a["u"][same], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(b["v"][same], a["v"][same], rtol=1e-4, atol=2e-5)
+    assert ties <= 8
+
+
+def test_quality_tree_costs_less(scene, batches):
+    """One pair per leaf: fewer pair tests, fewer algorithmic bytes even on a scene too small for the
+    re-insertion to find much."""
+    base = orc.traverse(batches["base"], batches["diffuse"], counters=True)
+    q1 = orc.traverse(ra.HostScene(scene["vertices"], scene["indices"], quality=1).blobs(), batches["diffuse"], counters=True)
+    q2 = orc.traverse(ra.HostScene(scene["vertices"], scene["indices"], quality=2).blobs(), batches["diffuse"], counters=True)
+    npairs = [float(r[2].mean()) for r in (base, q1, q2)]
+    assert npairs[1] < 0.9 * npairs[0] and npairs[2] < 0.9 * npairs[0], npairs
+    bytes_ = [orc.algorithmic_bytes(r[0], r[1], r[2]) for r in (base, q1, q2)]
+    assert bytes_[1] < bytes_[0] and bytes_[2] < bytes_[0]
+
+
+def test_quality_tree_of_the_bench_scene_needs_fewer_visits():
+    """battlefield-synth at full size, every fourth ray of the 1M first-bounce batch: >= 8 % fewer inner-node visits,
+    >= 15 % fewer pair tests than the reference builder's tree (measured: 51.1 -> 45.9 and 3.45 -> 2.69)."""
+    sc = synth.battlefield_synth()
+    base = ra.HostScene(sc["vertices"], sc["indices"])
+    prim, _ = synth.primary_rays(sc["camera"], 1024, 1024)
+    ref = orc.traverse(base.blobs(), prim, threads=8)
+    diff = synth.diffuse_bounce_rays(sc, prim, ref, 1 << 20)[::4].copy()
+    q1 = ra.HostScene(sc["vertices"], sc["indices"], quality=1)
+    a = orc.traverse(base.blobs(), diff, counters=True)
+    b = orc.traverse(q1.blobs(), diff, counters=True)
+    assert b[1].mean() < 0.92 * a[1].mean(), (a[1].mean(), b[1].mean())
+    assert b[2].mean() < 0.85 * a[2].mean(), (a[2].mean(), b[2].mean())
+    assert np.array_equal(a[0]["triangle"] == MISS, b[0]["triangle"] == MISS) or ((a[0]["triangle"] == MISS) != (b[0]["triangle"] == MISS)).sum() <= 4
+    both = (a[0]["triangle"] != MISS) & (b[0]["triangle"] != MISS)
+    other = both & (a[0]["triangle"] != b[0]["triangle"])
+    assert other.sum() <= 8 and np.allclose(a[0]["t"][other], b[0]["t"][other], rtol=1e-6, atol=0)
+    same = both & ~other
+    np.testing.assert_allclose(b[0]["t"][same], a[0]["t"][same], rtol=1e-4, atol=0)
+
+
+def test_tiny_and_degenerate_inputs():
+    """3 triangles (the smallest scene the format holds), a scene of unconnected triangles (no pair merges at all), and a
+    leaf-sized cluster of coincident triangles (zero-area boxes: the forced-median path, Bvh2.cpp:467-485)."""
+    v = np.array([[0, 0, 0, 1], [1, 0, 0, 1], [0, 1, 0, 1], [5, 0, 0, 1], [6, 0, 0, 1], [5, 1, 0, 1], [0, 0, 9, 1], [1, 0, 9, 1], [0, 1, 9, 1]], np.float32)
+    idx = np.arange(9, dtype=np.uint32)
+    sc = dict(vertices=v, indices=idx.reshape(-1, 3))
+    for q in (1, 2):
+        check_tree(ra.HostScene(v, idx, quality=q), sc, one_pair_leaves=True)
+    rng = np.random.default_rng(5)
+    v = np.concatenate([rng.uniform(-10, 10, (300, 3)).astype(np.float32), np.ones((300, 1), np.float32)], 1)
+    idx = np.arange(300, dtype=np.uint32)
+    sc = dict(vertices=v, indices=idx.reshape(-1, 3))
+    hs = ra.HostScene(v, idx, quality=1)
+    check_tree(hs, sc, one_pair_leaves=True)
+    assert hs.pair_count == 100
+    v = np.tile(np.array([[0, 0, 0, 1], [1, 0, 0, 1], [0, 1, 0, 1]], np.float32), (40, 1))
+    idx = np.arange(120, dtype=np.uint32)
+    sc = dict(vertices=v, indices=idx.reshape(-1, 3))
+    check_tree(ra.HostScene(v, idx, quality=1), sc, one_pair_leaves=True)
+
+
+def test_options_are_validated(scene):
+    lib = ra.load_library()
+    v = ra.engine._as_verts4(scene["vertices"])
+    idx = np.ascontiguousarray(scene["indices"], np.uint32).reshape(-1)
+    h = C.c_void_p()
+    opt = ra.engine.HostBuildOptions(struct_size=0, quality=1)
+    assert lib.racc_host_scene_build_ex(ra.engine._ptr(v), len(v), ra.engine._ptr(idx), idx.size, C.byref(opt), C.byref(h)) == -1 and not h
+    assert b"struct_size" in lib.racc_hip_last_error()
+    opt = ra.engine.HostBuildOptions(struct_size=C.sizeof(ra.engine.HostBuildOptions), quality=3)
+    assert lib.racc_host_scene_build_ex(ra.engine._ptr(v), len(v), ra.engine._ptr(idx), idx.size, C.byref(opt), C.byref(h)) == -1 and not h
+    assert b"quality" in lib.racc_hip_last_error()
+    # a caller compiled against a shorter struct (only struct_size + quality): the rest reads as 0
+    opt = ra.engine.HostBuildOptions(struct_size=8, quality=1, threads=77)
+    assert lib.racc_host_scene_build_ex(ra.engine._ptr(v), len(v), ra.engine._ptr(idx), idx.size, C.byref(opt), C.byref(h)) == 0 and h
+    lib.racc_host_scene_free(h)

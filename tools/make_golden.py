@@ -6,7 +6,7 @@ image, so these vectors come from oracle/racc_oracle.c (the CPU restatement), cr
 the double-precision brute-force arbiter before they are written.  They protect against regressions;
 they do NOT pin the oracle to the reference ("parity unpinned").
 
-    python tools/make_golden.py            # rewrites tests/golden/golden_small.{npz,json}, algorithmic_bytes.json
+    python tools/make_golden.py [--xl]     # rewrites tests/golden/golden_small.{npz,json}, algorithmic_bytes.json (--xl: the XL entries of the quality tree too)
 """
 import json
 import os
@@ -60,8 +60,51 @@ def full_bytes():
         r2, nv2, np2, d2 = orc.traverse(blobs, b, counters=True)
         out["diffuse_1M_sample%d" % s] = dict(bytes=orc.algorithmic_bytes(r2, nv2, np2), nv_mean=float(nv2.mean()), np_mean=float(np2.mean()),
                                              hit_rate=float((r2["triangle"] != 0xFFFFFFFF).mean()), max_stack=int(d2.max()))
-    json.dump(out, open(os.path.join(OUT, "algorithmic_bytes.json"), "w"), indent=1)
+    path = os.path.join(OUT, "algorithmic_bytes.json")
+    try:        # sections other functions maintain (the XL entries; the quality trees) survive a rewrite
+        old = json.load(open(path))
+        for k in ("xl_1M", "xl_diffuse_1M", "quality1", "quality2"):
+            if k in old:
+                out[k] = old[k]
+    except (OSError, ValueError):
+        pass
+    json.dump(out, open(path, "w"), indent=1)
     print(out)
+
+
+def quality_bytes(quality=1, xl=False):
+    """The same figures on the blobs of racc_host_scene_build_ex(quality): the PRODUCT's builder makes these trees (the reference has
+    no such mode, the oracle restates none) — the oracle traverses them, in the reference's order, and counts."""
+    import rayaccel_amd as ra
+    path = os.path.join(OUT, "algorithmic_bytes.json")
+    out = json.load(open(path))
+    sec = out.setdefault("quality%d" % quality, {})
+    sc = synth.battlefield_synth()
+    host = ra.HostScene(sc["vertices"], sc["indices"], quality=quality)
+    base = ra.HostScene(sc["vertices"], sc["indices"])
+    prim, _ = synth.primary_rays(sc["camera"], 1024, 1024)
+    res0 = orc.traverse(base.blobs(), prim, threads=8)          # the bench bounces off the primaries' hits; any tree finds the same ones
+    res, nv, npairs, depth = orc.traverse(host.blobs(), prim, counters=True, threads=8)
+    sec.update(scene=sc["name"], inner_nodes=len(host.nodes), pairs=host.pair_count,
+               what="racc_host_build_options.quality = %d (rayaccel_amd/csrc/scene_build.cpp): one pair per leaf + re-inserted subtrees; reference format, reference traversal order" % quality,
+               coherent_1M=dict(bytes=orc.algorithmic_bytes(res, nv, npairs), nv_mean=float(nv.mean()), np_mean=float(npairs.mean()),
+                                hit_rate=float((res["triangle"] != 0xFFFFFFFF).mean()), max_stack=int(depth.max())))
+    for s, b in enumerate(synth.diffuse_bounce_batches(sc, prim, res, 1 << 20, range(2))):
+        r2, nv2, np2, d2 = orc.traverse(host.blobs(), b, counters=True, threads=8)
+        sec["diffuse_1M_sample%d" % s] = dict(bytes=orc.algorithmic_bytes(r2, nv2, np2), nv_mean=float(nv2.mean()), np_mean=float(np2.mean()),
+                                              hit_rate=float((r2["triangle"] != 0xFFFFFFFF).mean()), max_stack=int(d2.max()))
+    del res0
+    if xl:
+        sx = synth.battlefield_synth_xl()
+        hx = ra.HostScene(sx["vertices"], sx["indices"], quality=quality)
+        hits = orc.traverse(hx.blobs(), prim, threads=8)
+        for key, rays in (("xl_1M", synth.random_rays(1 << 20, 7)), ("xl_diffuse_1M", synth.diffuse_bounce_rays(sx, prim, hits, 1 << 20))):
+            r2, nv2, np2, d2 = orc.traverse(hx.blobs(), rays, counters=True, threads=8)
+            sec[key] = dict(bytes=orc.algorithmic_bytes(r2, nv2, np2), nv_mean=float(nv2.mean()), np_mean=float(np2.mean()),
+                            hit_rate=float((r2["triangle"] != 0xFFFFFFFF).mean()), max_stack=int(d2.max()),
+                            inner_nodes=len(hx.nodes), pairs=hx.pair_count, scene=sx["name"])
+    json.dump(out, open(path, "w"), indent=1)
+    print(sec)
 
 
 if __name__ == "__main__":
@@ -69,3 +112,4 @@ if __name__ == "__main__":
     small()
     if "--no-full" not in sys.argv:
         full_bytes()
+        quality_bytes(1, xl="--xl" in sys.argv)

@@ -9,11 +9,12 @@
 #   pmcc_<i>              the same for the coherent primary batch (--workload coherent), fewer sets
 #   pmcv_<i>              the same for the compressed 4-wide kernel (kernel_variant 50), diffuse batch, fewer sets
 #   pmcx_<i>              FETCH_SIZE / WRITE_SIZE in the timed region's own mode (three lanes, chained); rocprofv3 serialises dispatches under --pmc
+#   stats_one_lane_q0, pmcq_<i>, stats_one_lane_xl_q0, pmcxq_<i>   the reference builder's tree (--quality 0; every other pass runs bench.py's default, quality 1)
 #   pmcxl_<i>, pmcxd_<i>  battlefield-synth-XL (1.3 GB on the device: past the Infinity Cache), 1M incoherent rays / the camera's 1M diffuse rays, one lane, no chaining
 # RACC_BENCH_ISO_LAUNCHES=0: no isolated launches before the warm-up, so the LAST 20 traversal dispatches of every pass are the 20 timed
 # steps (tools/summarize_profile.py selects them from the end; round 3's passes picked rows 4..23, which fell inside the isolated block).
 export RACC_BENCH_ISO_LAUNCHES=0
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -47,6 +48,13 @@ i=0
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1)); pass pmcx $i "$set"
 done
+# the reference builder's tree (--quality 0) under the same kernel: what the tree post-processing changes in the counters
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_lane_q0" -- $CMD --quality 0 --engine-opts "$ONE" > "$OUT/stats_one_lane_q0.log" 2>&1
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_INSTS_VMEM_WR" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY" "GRBM_GUI_ACTIVE GRBM_COUNT" "TA_TA_BUSY_sum TD_TD_BUSY_sum"; do
+  i=$((i+1)); pass pmcq $i "$set" --quality 0 --engine-opts "$ONE"
+done
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_lane_xl" -- $CMD --workload xl --engine-opts "$ONE" > "$OUT/stats_one_lane_xl.log" 2>&1
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_lane_xl_diffuse" -- $CMD --workload xl_diffuse --engine-opts "$ONE" > "$OUT/stats_one_lane_xl_diffuse.log" 2>&1
 passxl() {   # the XL scene takes ~20 s to build: its own, longer timeout
@@ -62,6 +70,11 @@ done
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE GRBM_COUNT" "TA_TA_BUSY_sum TD_TD_BUSY_sum"; do
   i=$((i+1)); passxl pmcxd $i "$set" --workload xl_diffuse --engine-opts "$ONE"
+done
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_lane_xl_q0" -- $CMD --workload xl --quality 0 --engine-opts "$ONE" > "$OUT/stats_one_lane_xl_q0.log" 2>&1
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "GRBM_GUI_ACTIVE GRBM_COUNT" "TA_TA_BUSY_sum TD_TD_BUSY_sum"; do
+  i=$((i+1)); passxl pmcxq $i "$set" --workload xl --quality 0 --engine-opts "$ONE"
 done
 find "$OUT" -name "*.csv" | wc -l
 du -sh "$OUT"

@@ -13,10 +13,13 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CUS, SIMDS, XCDS = 256, 1024, 8
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
+
+
+TIMED = {}      # per kernel-trace pass: the durations (ms) of the 20 timed traversal dispatches the means below are taken over
 
 
 def newest(pattern):
@@ -34,6 +37,7 @@ def trace_durations(sub):
     if len(rows) < 20:
         return rows, None
     timed = rows[-20:]
+    TIMED[sub] = [round(d, 5) for d in dur[-20:]]
     span = (max(int(r["End_Timestamp"]) for r in timed) - min(int(r["Start_Timestamp"]) for r in timed)) / 1e6
     return rows, dict(kernel=timed[0]["Kernel_Name"], timed_mean_ms=float(np.mean(dur[-20:])), timed_min_ms=float(np.min(dur[-20:])),
                       timed_span_ms_per_launch=span / 20.0, launches=len(rows),
@@ -81,7 +85,6 @@ def derive(c, trace, rays=1 << 20):
         if g("TD_TD_BUSY_sum"): der["td_busy_frac"] = round(g("TD_TD_BUSY_sum") / (CUS * cycles), 4)
         if g("TA_TA_BUSY_sum"): der["ta_busy_frac"] = round(g("TA_TA_BUSY_sum") / (CUS * cycles), 4)
         if g("SQ_ACTIVE_INST_VALU"): der["valu_busy_frac"] = round(4 * g("SQ_ACTIVE_INST_VALU") / (SIMDS * cycles), 4)
-        if g("SQ_ACTIVE_INST_ANY"): der["issue_slot_frac"] = round(4 * g("SQ_ACTIVE_INST_ANY") / (SIMDS * cycles), 4)
     if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
         der["valu_lane_util"] = round(g("SQ_THREAD_CYCLES_VALU") / (64 * g("SQ_ACTIVE_INST_VALU")), 4)
     insts = [g(k) or 0.0 for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM")]
@@ -102,21 +105,22 @@ def derive(c, trace, rays=1 << 20):
 out = {}
 for sub, name in (("stats", "kernel_stats.csv"), ("stats_one_lane", "kernel_stats_one_lane.csv"), ("stats_one_lane_coherent", "kernel_stats_one_lane_coherent.csv"),
                   ("stats_one_lane_v10", "kernel_stats_one_lane_v10.csv"), ("stats_one_lane_xl", "kernel_stats_one_lane_xl.csv"),
-                  ("stats_one_lane_xl_diffuse", "kernel_stats_one_lane_xl_diffuse.csv")):
+                  ("stats_one_lane_xl_diffuse", "kernel_stats_one_lane_xl_diffuse.csv"), ("stats_one_lane_q0", "kernel_stats_one_lane_q0.csv"),
+                  ("stats_one_lane_xl_q0", "kernel_stats_one_lane_xl_q0.csv")):
     s_ = newest(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
     if s_:
         shutil.copy(s_, os.path.join(dst, name))
 _, out["kernel_trace"] = trace_durations("stats")
 traces = {k: trace_durations(sub)[1] for k, sub in (("diffuse", "stats_one_lane"), ("coherent", "stats_one_lane_coherent"), ("v10_diffuse", "stats_one_lane_v10"),
-                                                    ("xl", "stats_one_lane_xl"), ("xl_diffuse", "stats_one_lane_xl_diffuse"))}
+                                                    ("xl", "stats_one_lane_xl"), ("xl_diffuse", "stats_one_lane_xl_diffuse"),
+                                                    ("q0_diffuse", "stats_one_lane_q0"), ("q0_xl", "stats_one_lane_xl_q0"))}
 out["kernel_trace_one_lane"] = traces
 pm = {"diffuse": counters("pmc"), "coherent": counters("pmcc"), "v10_diffuse": counters("pmcv"), "diffuse_chained": counters("pmcx", sum_timed=True),
-      "xl": counters("pmcxl"), "xl_diffuse": counters("pmcxd")}
+      "xl": counters("pmcxl"), "xl_diffuse": counters("pmcxd"), "q0_diffuse": counters("pmcq"), "q0_xl": counters("pmcxq")}
 out["counters"] = pm
-h = hashlib.sha256()
-for rel in ("rayaccel_amd/csrc/racc_kernel_v8.inc", "rayaccel_amd/csrc/racc_device.inc"):
-    h.update(open(os.path.join(ROOT, rel), "rb").read())
-out["kernel_source_sha256"] = h.hexdigest()
+sys.path.insert(0, ROOT)
+import bench      # the list of files the counters depend on lives there (KERNEL_SOURCES)
+out["kernel_source_sha256"] = bench.kernel_source_sha256()
 out["kernel_v10_source_sha256"] = hashlib.sha256(open(os.path.join(ROOT, "rayaccel_amd/csrc/racc_kernel_v10.inc"), "rb").read()).hexdigest()
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 
@@ -132,13 +136,12 @@ der = dict(kernel_source_sha256=out["kernel_source_sha256"], kernel_v10_source_s
                td_busy_frac="TD_TD_BUSY_sum / (256 CUs * GRBM_GUI_ACTIVE / 8 XCDs)",
                ta_busy_frac="TA_TA_BUSY_sum / (256 CUs * cycles)",
                valu_busy_frac="4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * cycles)   (the counter is in quad-cycles)",
-               issue_slot_frac="4 * SQ_ACTIVE_INST_ANY / (1024 SIMDs * cycles)",
                valu_lane_util="SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)",
                salu_share="SQ_INSTS_SALU / (SQ_INSTS_VALU + SQ_INSTS_SALU + SQ_INSTS_VMEM_RD + SQ_INSTS_VMEM_WR + SQ_INSTS_LDS + SQ_INSTS_SMEM)",
                l2_hit_rate="TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)",
                vmem_rd_insts_per_ray="SQ_INSTS_VMEM_RD / 2^20 rays (wave-level instructions)",
                fabric_bytes_per_step_chained="(2 * sum FETCH_SIZE + sum WRITE_SIZE) * 1024 over the traversal dispatches of the 20 timed steps / 20, three lanes, chained (rocprofv3 serialises dispatches under --pmc)"))
-for key in ("diffuse", "coherent", "v10_diffuse", "xl", "xl_diffuse"):
+for key in ("diffuse", "coherent", "v10_diffuse", "xl", "xl_diffuse", "q0_diffuse", "q0_xl"):
     der[key] = derive(pm[key], traces.get(key))
 cx = pm["diffuse_chained"]
 if cx.get("FETCH_SIZE") and cx.get("WRITE_SIZE"):
@@ -151,8 +154,13 @@ if d0.get("SQ_INSTS_VMEM_RD_per_launch") and d1.get("SQ_INSTS_VMEM_RD_per_launch
                                  kernel_ms=round(d1["kernel_ms_isolated"] / d0["kernel_ms_isolated"], 3) if d0.get("kernel_ms_isolated") and d1.get("kernel_ms_isolated") else None)
 # copies of the microbenchmark outputs taken on the same box (tools/microbench/run_microbench.sh <tag>)
 mb = os.path.join(ROOT, "gpurun_out", "microbench_" + tag)
-for f in ("gather64.txt", "gather128.txt", "scatter16.txt", "microbench.json"):
+for f in ("gather64.txt", "gather128.txt", "scatter16.txt", "fetchcal.txt", "fetchcal.json", "microbench.json"):
     if os.path.exists(os.path.join(mb, f)):
         shutil.copy(os.path.join(mb, f), os.path.join(dst, f))
+der["tree"] = "diffuse / coherent / v10_diffuse / xl / xl_diffuse: racc_host_build_options.quality = 1 (bench.py's default); q0_diffuse / q0_xl: the reference builder's tree (--quality 0), same kernel, same rays"
+# kernel_stats*.csv are rocprofv3's own aggregates over EVERY dispatch of a pass (the primary batch's slices and the warm-up steps included);
+# the means in derived.json are over the 20 timed dispatches only — listed here so that they can be recomputed from a committed file
+json.dump(dict(what="durations in ms of the last 20 traversal dispatches of each kernel-trace pass (= the 20 timed steps)", passes=TIMED),
+          open(os.path.join(dst, "timed_dispatches.json"), "w"), indent=1)
 json.dump(der, open(os.path.join(dst, "derived.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in der.items() if k != "formulas"}, indent=1))
