@@ -40,7 +40,7 @@ PCIE_GBS_PER_DIRECTION = 56.0  # page-locked copies on the GPU boxes, one direct
 # rocprofv3 summaries of THIS command (tools/profile_bench.sh <round>) + microbenchmark outputs: the latest round's that is committed
 PROFILE_DIR = next(os.path.join("profiles", r) for r in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "derived.json")))
 # what the committed counters depend on: the kernel, its launch policy (chunk, grid, chain), the device node order — and the tree builder
-KERNEL_SOURCES = ("rayaccel_amd/csrc/racc_kernel_v8.inc", "rayaccel_amd/csrc/racc_device.inc", "rayaccel_amd/csrc/racc_launch.inc",
+KERNEL_SOURCES = ("rayaccel_amd/csrc/racc_kernel_v8.inc", "rayaccel_amd/csrc/racc_kernel_v8_hot.inc", "rayaccel_amd/csrc/racc_device.inc", "rayaccel_amd/csrc/racc_launch.inc",
                   "rayaccel_amd/csrc/racc_scene_format.inc", "rayaccel_amd/csrc/racc_hip.hip", "rayaccel_amd/csrc/scene_build.cpp")
 CU_CLOCK_HZ, CUS = 2.4e9, 256
 
@@ -275,10 +275,33 @@ def main():
             sys.exit("bench: step %d of the timed region produced other results than step %d (same rays)" % (k, k % len(d_sets)))
     per_rank, comm_ranks = [elapsed], 1
     if world > 1:
+        # SCALE-day hardening: rank 0's line must not depend on another rank's teardown.  If the gather of the elapsed times has not come back
+        # after RACC_BENCH_GATHER_TIMEOUT seconds (default 120; a rank died, the fabric hangs), rank 0 prints a line from ITS OWN elapsed time,
+        # marked "partial": true, and the process exits — instead of hanging until the driver's limit with nothing on stdout.
+        import threading
+        gather_timeout = float(os.environ.get("RACC_BENCH_GATHER_TIMEOUT", "120"))
+
+        def give_up():
+            if rank == 0:
+                print(json.dumps({"metric": "Mrays/s", "value": round(total_rays * args.steps / elapsed / 1e6, 1), "unit": "Mrays/s", "n_gpus": world,
+                                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+                                  "scaling": args.mode, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "partial": True,
+                                  "partial_reason": "the all-gather of the ranks' elapsed times did not return within %.0f s: value = all ranks' rays over RANK 0's own time, "
+                                                    "not the maximum over ranks" % gather_timeout,
+                                  "config": {"workload": "battlefield-synth (stand-in), 1M 1st-bounce diffuse rays per GPU per step", "rays_per_gpu": n}}), flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(gather_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         cdev = "cuda" if backend == "nccl" else "cpu"
         mine = torch.tensor([elapsed, 1.0], dtype=torch.float64, device=cdev)
         every = [torch.zeros_like(mine) for _ in range(world)]
+        if os.environ.get("RACC_BENCH_TEST_HANG") == str(rank):      # (tests: this rank never joins the gather)
+            time.sleep(3600)
         dist.all_gather(every, mine)                                   # RCCL over xGMI when backend == nccl
+        if cdev == "cuda":
+            torch.cuda.synchronize()
+        watchdog.cancel()
         per_rank = [float(t[0].item()) for t in every]
         comm_ranks = int(round(sum(float(t[1].item()) for t in every)))      # ranks that took part in the collective
         elapsed = max(per_rank)
@@ -453,9 +476,21 @@ def main():
             tmp.close()
             try:
                 synth.write_scene_bin(tmp.name, sc, viewport=(1920, 1080))
+                os.environ["RACC_BUILD_QUALITY"] = str(args.quality)      # the consumers build their own scene through racc_host_scene_build: same tree as the headline
                 _, sg = path_trace(tmp.name, 1920, 1080, 0, 64, device=device, shading="gpu")
                 _, sh = path_trace(tmp.name, 1920, 1080, 0, 8, device=device, shading="cpu", cpu_threads=usable_cores())
+                # racc::render with callbacks that cost nothing (spawn = memcpy of a pre-generated 128x128 tile, shade empty): what the ray-stream
+                # state machine + the host RayStream path sustain by themselves — the ceiling of the drop-in API (tests/cpp/render_check.cpp)
+                sched = None
+                try:
+                    import subprocess
+                    pr = subprocess.run([os.path.join(ROOT, "tests", "cpp", "render_check"), tmp.name, "--null-callbacks", "1920", "1080", "16", "4"],
+                                        capture_output=True, text=True, timeout=300, env=dict(os.environ, RACC_CPU_THREADS=str(usable_cores())))
+                    sched = json.loads(pr.stdout.strip().splitlines()[-1]) if pr.returncode == 0 else {"error": (pr.stderr or pr.stdout)[-300:]}
+                except Exception as e:   # noqa: BLE001
+                    sched = {"error": str(e)[:200]}
                 extras["path_tracer_1080p"] = {
+                    "scheduler_only_null_callbacks": sched,
                     "gpu_shading_64spp": {"mrays_per_s": round(sg["rays_traced"] / sg["seconds"] / 1e6, 1), "seconds": round(sg["seconds"], 4), "rays": int(sg["rays_traced"])},
                     "host_shading_8spp": {"mrays_per_s": round(sh["rays_traced"] / sh["seconds"] / 1e6, 1), "seconds": round(sh["seconds"], 4), "rays": int(sh["rays_traced"]),
                                           "shade_threads": int(sh["threads"])}}

@@ -189,7 +189,10 @@ int racc_hip_intersect_streams_async(racc_hip_ctx* ctx, const racc_hip_scene* sc
  * under the next one's bulk — which is how the reference keeps its gpuSubmissionThreads queues busy
  * (RayAccelerator.cpp:711-717).  lane = RACC_HIP_LANE_AUTO rotates over the lanes, so a single-threaded caller that issues
  * batch after batch (stream = NULL) gets that overlap without managing lanes; racc_hip_wait(ctx, RACC_HIP_LANE_AUTO) or
- * racc_hip_synchronize then waits for all of them.
+ * racc_hip_synchronize then waits for all of them.  A launch of <= 2M rays issued while ANOTHER lane has a launch the host has not
+ * waited for takes a thin grid (2 waves per SIMD instead of 5), so that up to three launches are co-resident; "in flight" is what the
+ * caller has issued and not yet waited for — a property of the call sequence, not of the GPU's progress at that instant: wait for a
+ * lane (racc_hip_wait) before issuing a launch that should have the machine to itself.
  * With stream = NULL the batch must be resident and final at the call, and — racc_hip_options::chain_launches, the default, for
  * batches of at least racc_hip_options::chain_min_rays rays (786,432) —
  * launches are CHAINED: waves of the launches issued before may start on this batch at once and carry on through it, so that
@@ -231,11 +234,12 @@ int racc_hip_get_launch_info(racc_hip_ctx* ctx, uint32_t lane, racc_hip_launch_i
 /* With racc_hip_options::time_kernels: durations (ms, HIP events on the stream each launch went to) of the lane's traversal
  * kernels since the last call, oldest first, at most `capacity` (the engine keeps the last 256); *n = how many.  Waits for them. */
 int racc_hip_read_kernel_times(racc_hip_ctx* ctx, uint32_t lane, float* ms, uint32_t capacity, uint32_t* n);
-/* Scheduling statistics accumulated by the debug kernel variant (kernel_variant 9) on a lane:
- * [0] inner-step iterations [1] lanes active in them [2] leaf-step iterations [3] lanes active in them
+/* Scheduling statistics accumulated by the statistics build of the default kernel (kernel_variant 42) on a lane:
+ * [0] inner steps (wave-level) [1] lanes live in them [2] leaf steps [3] lanes live in them
  * [4] refill iterations [5] rays loaded [6] cursor dequeues [7] waves; shader-clock cycles summed over waves:
- * [8] inner iterations [9] of which node-fetch wait [10] leaf iterations [11] of which pair-fetch wait
- * [12] refill iterations [13] wave lifetime; [14..15] reserved.  stats16 has 16 entries.  Waits for the lane. */
+ * [8],[10] unused by variant 42 [12] refill iterations [13] wave lifetime;
+ * [14] inner steps in which ALL live inner lanes hold the same node (what a wave-uniform scalar step could serve)
+ * [15] inner steps fetched quad-cooperatively.  stats16 has 16 entries.  Waits for the lane. */
 int racc_hip_read_stats(racc_hip_ctx* ctx, uint32_t lane, uint64_t* stats16, int reset);
 
 /* Device memory helpers for hosts that do not bring their own allocator. */
@@ -306,7 +310,9 @@ int racc_hip_comm_destroy(racc_hip_comm* comm);
  * ≙ the GPU branch of racc::createScene, Scene.cpp:216-339: createBvh2 (Bvh2.cpp:772-907) →
  * leaf pair merge (Scene.cpp:237-261) → 64 B node flatten (Scene.cpp:275-332) → pair padding
  * (Scene.cpp:334-338).  vertices: xyzw floats, 16-byte aligned (Scene.cpp:187); index_count % 3 == 0
- * (Scene.cpp:186).  Deterministic (the reference's node numbering is thread-timing dependent). */
+ * (Scene.cpp:186).  Deterministic (the reference's node numbering is thread-timing dependent).
+ * = racc_host_scene_build_ex with options NULL: the reference's builder, unless the environment variable RACC_BUILD_QUALITY
+ * (0, 1, 2) asks for a quality tree — the switch for callers that pass no options (racc::createScene, the path-tracing consumers). */
 int racc_host_scene_build(const float* vertices, uint32_t vertex_count,
                           const uint32_t* indices, uint32_t index_count,
                           racc_host_scene** out);

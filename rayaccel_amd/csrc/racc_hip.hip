@@ -124,6 +124,11 @@ struct Lane {
     hipEvent_t done = nullptr;
     hipStream_t lastStream = nullptr;
     std::atomic<bool> everLaunched{false};
+    // Host-side knowledge of work in flight: set when a traversal launch is enqueued on this lane, cleared when the host has waited for the
+    // lane (racc_hip_wait, the blocking entries, racc_hip_synchronize).  What sizes an overlapping launch's grid (launchTraverse): it depends
+    // on what the CALLER has issued and not yet waited for — not on whether the GPU happens to have finished it at this instant
+    // (rounds 2-4 asked hipEventQuery: the same call sequence could come out with different grids from run to run).
+    std::atomic<bool> launchPending{false};
     // opts.time_kernels: an event pair around every traversal kernel, read back by racc_hip_read_kernel_times
     std::vector<hipEvent_t> ring;        // 2 * kTimeRing events
     uint32_t ringHead = 0, ringCount = 0;
@@ -531,6 +536,7 @@ int racc_hip_intersect_device_timed(racc_hip_ctx* ctx, const racc_hip_scene* sce
     for (uint32_t i = 0; i < iters; ++i)
         HIP_TRY(hipEventElapsedTime(&ms[i], l.events[2 * i], l.events[2 * i + 1]), "hipEventElapsedTime");
     l.info.last_kernel_ms = ms[iters - 1];
+    l.launchPending.store(false, std::memory_order_release);
     return checkWatchdog(ctx);
 }
 
@@ -638,6 +644,10 @@ int racc_hip_synchronize(racc_hip_ctx* ctx) {
     if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
+        ctx->lanes[i].launchPending.store(false, std::memory_order_release);
+        for (Lane* h : ctx->lanes[i].helper) if (h) h->launchPending.store(false, std::memory_order_release);
+    }
     return checkWatchdog(ctx);
 }
 

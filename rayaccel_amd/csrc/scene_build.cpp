@@ -820,6 +820,10 @@ int racc_host_scene_build_ex(const float* vertices, uint32_t vertex_count,
     if (options) {
         if (options->struct_size < 8 || options->struct_size > 4096) { set_error("racc_host_build_options.struct_size is not set"); return RACC_HIP_ERR_INVALID; }
         std::memcpy(&opt, options, std::min<size_t>(options->struct_size, sizeof(opt)));
+    } else if (const char* e = std::getenv("RACC_BUILD_QUALITY")) {
+        // callers without options (racc_host_scene_build: racc::createScene, the path-tracing consumers) can be switched from outside
+        const long q = std::atol(e);
+        opt.quality = q > 0 ? uint32_t(q) : 0u;
     }
     if (opt.quality > 2) { set_error("racc_host_build_options.quality must be 0, 1 or 2"); return RACC_HIP_ERR_INVALID; }
     *out = nullptr;

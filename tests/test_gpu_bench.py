@@ -67,3 +67,17 @@ def test_plain_command_with_two_gpus_spawns_its_own_ranks():
     assert d["n_gpus"] == 2 and d["comm_ranks"] == 2 and d["collective_backend"] == "gloo" and d["rccl_ranks"] is None
     assert len(d["per_rank_mrays_per_s"]) == 2 and all(v > 0 for v in d["per_rank_mrays_per_s"])
     assert d["value"] <= sum(d["per_rank_mrays_per_s"]) * 1.001          # whole-job rate = all rays / the slowest rank's time
+
+
+def test_a_rank_that_never_joins_the_final_gather_does_not_silence_rank_0():
+    """SCALE-day hardening (round-4 verdict, item 7): if the all-gather of the ranks' elapsed times hangs (a rank died, the fabric stalls),
+    rank 0 prints its line with "partial": true after RACC_BENCH_GATHER_TIMEOUT seconds instead of hanging silently.  Two gloo ranks on
+    GPU 0; rank 1 is told never to enter the gather."""
+    env = dict(os.environ, RACC_BENCH_BACKEND="gloo", RACC_BENCH_DEVICE="0", RACC_BENCH_TEST_HANG="1", RACC_BENCH_GATHER_TIMEOUT="8")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29551", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--grid", "128", "--no-extras"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-1000:] + p.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["partial"] is True and d["n_gpus"] == 2 and d["value"] > 0 and "did not return" in d["partial_reason"]

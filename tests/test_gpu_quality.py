@@ -82,24 +82,27 @@ def test_full_size_1M_coherent_and_diffuse_on_the_quality_tree(gpu_ctx, full, fu
 
 def test_chained_device_batches_on_the_quality_tree(full, full_q1):
     """The bench's own loop on a default-options context (batches of >= 786,432 rays are chained): 24 device-resident 1M-ray batches,
-    eight sample sets in rotation, issued back to back over the lanes, every record of every batch against the oracle."""
-    import torch
+    eight sample sets in rotation, issued back to back over the lanes, every record of every batch against the oracle.
+    (Device arrays through the engine's own allocator: importing torch into this process would load a second HIP runtime.)"""
     sc, host = full["sc"], full_q1["host"]
+    n = 1 << 20
     with ra.Context(device=0) as ctx:
         scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
         env = ctx.create_environment(sc["env"])
         hits = ctx.intersect(scene, env, full["primary"])
-        sets = synth.diffuse_bounce_batches(sc, full["primary"], hits, 1 << 20, range(8))
+        sets = synth.diffuse_bounce_batches(sc, full["primary"], hits, n, range(8))
         refs = [orc.traverse(full_q1["blobs"], r, env=sc["env"], threads=8) for r in sets]
-        d_sets = [torch.from_numpy(r.view(np.float32).reshape(-1, 8).copy()).cuda() for r in sets]
-        outs = [torch.zeros((1 << 20, 4), dtype=torch.float32, device="cuda") for _ in range(24)]
-        torch.cuda.synchronize()
+        d_sets = []
+        for r in sets:
+            d = ctx.alloc(r.nbytes); d.upload(r); d_sets.append(d)
+        outs = [ctx.alloc(n * 16) for _ in range(24)]
         for k in range(24):
-            ctx.intersect_device(scene, env, d_sets[k % 8].data_ptr(), outs[k].data_ptr(), 1 << 20, lane=ra.LANE_AUTO)
+            ctx.intersect_device(scene, env, d_sets[k % 8].ptr, outs[k].ptr, n, lane=ra.LANE_AUTO)
         ctx.wait(ra.LANE_AUTO)
-        torch.cuda.synchronize()
         for k in range(24):
-            assert_bit_exact(outs[k].cpu().numpy().view(ra.RESULT_DTYPE).reshape(-1), refs[k % 8], "chained batch %d (sample set %d), quality 1" % (k, k % 8))
+            assert_bit_exact(outs[k].download(ra.RESULT_DTYPE, n), refs[k % 8], "chained batch %d (sample set %d), quality 1" % (k, k % 8))
+        for d in d_sets + outs:
+            d.free()
         scene.destroy(); env.destroy()
 
 
@@ -132,3 +135,50 @@ def test_wide_and_compressed_kernels_on_the_quality_tree(full, full_q1):
             arb = dict(vertices=sc["vertices"], indices=sc["indices"], rays=rays) if variant == 50 else None
             assert_same_closest_hit(got, ref, "variant %d on quality-1 blobs" % variant, arbiter=arb)
             scene.destroy(); env.destroy()
+
+
+def test_default_threshold_interleaves_chained_and_stand_alone_batches(full, full_q1):
+    """the suite's shared context chains every batch (chain_min_rays = 1), so the shipping default — batches of >= 786,432
+    rays chained, smaller ones stand-alone on the SAME lanes, sharing the lane's cursor and spill with the chain ring — was hardly run.
+    A default-options context, 1M-ray batches alternating with 64 ... 99,999-ray ones over RACC_HIP_LANE_AUTO, waits on single lanes and
+    on all of them in between, 280 chained launches in all (the 256-entry descriptor ring laps), every record of every batch compared."""
+    sc, host = full["sc"], full_q1["host"]
+    n = 1 << 20
+    rng = np.random.default_rng(11)
+    with ra.Context(device=0) as ctx:
+        scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
+        env = ctx.create_environment(sc["env"])
+        hits = ctx.intersect(scene, env, full["primary"])
+        sets = synth.diffuse_bounce_batches(sc, full["primary"], hits, n, range(3)) + [full["primary"]]
+        refs = [orc.traverse(full_q1["blobs"], r, env=sc["env"], threads=8) for r in sets]
+        d_sets = []
+        for r in sets:
+            d = ctx.alloc(r.nbytes); d.upload(r); d_sets.append(d)
+        big_outs = [ctx.alloc(n * 16) for _ in range(40)]
+        small_outs = [ctx.alloc(100000 * 16) for _ in range(40)]
+        chained = 0
+        for rnd in range(7):
+            issued = []
+            for k in range(40):
+                s = int(rng.integers(0, len(sets)))
+                ctx.intersect_device(scene, env, d_sets[s].ptr, big_outs[k].ptr, n, lane=ra.LANE_AUTO)
+                issued.append((big_outs[k], s, 0, n))
+                chained += 1
+                if k % 3 != 2:            # one or two small stand-alone batches behind it, on the lanes next in the rotation
+                    for _ in range(1 + k % 2):
+                        m = int(rng.choice([64, 1000, 27648, 99999]))
+                        off = int(rng.integers(0, n - m)) // 64 * 64
+                        slot = len([i for i in issued if i[0] in small_outs])
+                        if slot >= len(small_outs):
+                            break
+                        ctx.intersect_device(scene, env, d_sets[s].ptr + off * 32, small_outs[slot].ptr, m, lane=ra.LANE_AUTO)
+                        issued.append((small_outs[slot], s, off, m))
+                if k == 17:
+                    ctx.wait(1)           # a single lane in between: its batches are complete, the others stay in flight
+            ctx.wait(ra.LANE_AUTO)
+            for d_o, s, off, m in issued:
+                assert_bit_exact(d_o.download(ra.RESULT_DTYPE, m), refs[s][off:off + m], "round %d, set %d, %d rays at %d" % (rnd, s, m, off))
+        assert chained > 256
+        for d in d_sets + big_outs + small_outs:
+            d.free()
+        scene.destroy(); env.destroy()

@@ -114,3 +114,17 @@ def test_create_context_without_gpu_context_fails_loudly(tmp_path):
                            "-lrayaccelerator", "-lracc_hip", "-Wl,-rpath," + lib])
     p = subprocess.run([exe], capture_output=True, text=True)
     assert p.returncode == 0 and "RayAccelerator:" in p.stderr
+
+
+def test_null_callbacks_scheduler_rate(tmp_path, small_scene):
+    """render_check --null-callbacks: racc::render with callbacks that cost nothing (spawn = one memcpy of a pre-generated tile, shade
+    consumes and emits nothing) — the scheduler + host RayStream path alone (what bench.py reports as `scheduler_only_null_callbacks`).
+    Every spawned ray is traced and handed to shade exactly once; with RACC_BUILD_QUALITY=1 racc::createScene builds the quality tree."""
+    scene_file = os.path.join(str(tmp_path), "scene.bin")
+    synth.write_scene_bin(scene_file, small_scene)
+    for env in (dict(), dict(RACC_BUILD_QUALITY="1"), dict(RACC_CPU_THREADS="2", RACC_GPU_THREADS="1", RACC_BATCH="4096")):
+        p = subprocess.run([BIN, scene_file, "--null-callbacks", "1024", "512", "3", "3"], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stdout + p.stderr
+        info = json.loads(p.stdout.strip().splitlines()[-1])
+        assert info["raysTraced"] == info["consumed"] == 8 * 4 * 16384 * 3
+        assert info["mrays_per_s_best"] > 5.0

@@ -199,6 +199,17 @@ def test_tiny_and_degenerate_inputs():
     check_tree(ra.HostScene(v, idx, quality=1), sc, one_pair_leaves=True)
 
 
+def test_environment_switch_for_callers_without_options(scene, monkeypatch):
+    """RACC_BUILD_QUALITY: what racc::createScene and the path-tracing consumers (callers of the plain racc_host_scene_build) are switched with."""
+    q1 = ra.HostScene(scene["vertices"], scene["indices"], quality=1)
+    monkeypatch.setenv("RACC_BUILD_QUALITY", "1")
+    via_env = ra.HostScene(scene["vertices"], scene["indices"])
+    assert via_env.nodes.tobytes() == q1.nodes.tobytes() and via_env.pairs.tobytes() == q1.pairs.tobytes() and via_env.remap.tobytes() == q1.remap.tobytes()
+    explicit0 = ra.HostScene(scene["vertices"], scene["indices"], quality=0, threads=2)      # explicit options win over the environment
+    monkeypatch.delenv("RACC_BUILD_QUALITY")
+    assert explicit0.nodes.tobytes() == ra.HostScene(scene["vertices"], scene["indices"]).nodes.tobytes()
+
+
 def test_options_are_validated(scene):
     lib = ra.load_library()
     v = ra.engine._as_verts4(scene["vertices"])

@@ -7,10 +7,10 @@ import rayaccel_amd as ra
 from rayaccel_amd import synth
 from oracle import oracle as orc
 sc = synth.battlefield_synth()
-host = ra.HostScene(sc["vertices"], sc["indices"])
+host = ra.HostScene(sc["vertices"], sc["indices"], quality=int(os.environ.get("RACC_SWEEP_QUALITY", "1")))
 prim, _ = synth.primary_rays(sc["camera"], 1024, 1024)
 ref = orc.traverse(host.blobs(), prim, threads=16)
-diff = np.concatenate([synth.diffuse_bounce_rays(sc, prim, ref, 1 << 20, first_sample=s) for s in range(4)])
+diff = np.concatenate(synth.diffuse_bounce_batches(sc, prim, ref, 1 << 20, range(4)))
 combos = [json.loads(a) for a in sys.argv[1:]] or [dict()] + [dict(leaf_min=l, refill_min=r, inner_reps=i) for l in (6, 12, 20) for r in (20, 32, 44) for i in (2, 3, 5)] + [dict(tail_active=t) for t in (16, 24, 40, 48)] + [dict(chunk=c) for c in (32, 128, 256)]
 for opt in combos:
     with ra.Context(device=0, lanes=4, **opt) as ctx:
@@ -27,7 +27,7 @@ for opt in combos:
         best = 1e9
         for rep in range(3):
             t0 = time.perf_counter()
-            for k in range(40): ctx.intersect_device(scene, env, d_r.ptr, outs[k % 3].ptr, n1, lane=ra.LANE_AUTO)
+            for k in range(40): ctx.intersect_device(scene, env, d_r.ptr + (k % 4) * n1 * 32, outs[k % 3].ptr, n1, lane=ra.LANE_AUTO)
             ctx.wait(ra.LANE_AUTO)
             best = min(best, (time.perf_counter() - t0) / 40)
         small = {}
