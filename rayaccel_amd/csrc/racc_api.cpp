@@ -228,7 +228,22 @@ void gpuWorker(Context* c, unsigned worker) {   // reference gpuWorkerThread, :3
                 c->readyForTest.resize(c->readyForTest.size() - take);
             }
         } else if (!c->waitingToBeFilled.empty() && c->cpuBusy == 0 && c->readyForShade.empty() && spawnBlocked(c)) {
-            ids.swap(c->waitingToBeFilled);             // nothing on the CPU side can add rays any more: flush
+            // Nothing on the CPU side can add rays any more: flush the partly filled streams — but never ALL streams that can still take
+            // rays.  Shading a traced stream needs an output stream (reference :108); the reference's stream count (:518-521) guarantees one
+            // because a stream that has left the fill lists holds a full batch, and the rays in flight are bounded.  A flushed stream holds
+            // fewer, so that argument no longer counts them: with callbacks that cost nothing, every one of the streams ended up traced and
+            // waiting to be shaded with no stream left to shade into (round 5, render_check --null-callbacks: the frame hung once in ~8 runs).
+            // So the flush leaves `keep` streams behind — the emptiest ones — whenever the empty list cannot provide them; they go out with a
+            // later flush, once the flushed ones have been shaded and have come back empty.
+            const size_t keep = std::max<size_t>(1, std::min<size_t>(c->configuration.cpuThreads, c->streams.size() / 4));
+            const size_t spare = c->empty.size() >= keep ? 0 : keep - c->empty.size();
+            if (spare >= c->waitingToBeFilled.size()) {      // (all of them are needed as outputs: whoever is being traced or shaded now will free streams)
+                c->wake.wait(lock);
+                continue;
+            }
+            std::sort(c->waitingToBeFilled.begin(), c->waitingToBeFilled.end(), [c](uint32_t a, uint32_t b) { return c->streams[a].count < c->streams[b].count; });
+            ids.assign(c->waitingToBeFilled.begin() + spare, c->waitingToBeFilled.end());
+            c->waitingToBeFilled.resize(spare);
         } else {
             c->wake.wait(lock);
             continue;
@@ -489,7 +504,24 @@ Stats render(Context* c, Scene* scene, Environment* environment, RenderCallbacks
     c->currentCallbacks = callbacks;
     c->moreRaysExist = true;
     c->wake.notify_all();
-    c->wake.wait(lock, [c] { return !c->moreRaysExist && c->raysInFlight == 0 && c->cpuBusy == 0 && c->gpuBusy == 0; });
+    auto done = [c] { return !c->moreRaysExist && c->raysInFlight == 0 && c->cpuBusy == 0 && c->gpuBusy == 0; };
+    // RACC_RENDER_WATCHDOG_S=<seconds> (diagnostics): a frame that makes no progress for that long prints the scheduler's state and aborts
+    static const double limit = [] { const char* e = std::getenv("RACC_RENDER_WATCHDOG_S"); return e ? std::atof(e) : 0.0; }();
+    if (limit > 0.0) {
+        uint64_t lastCount = ~0ull;
+        while (!c->wake.wait_for(lock, std::chrono::duration<double>(limit), done)) {
+            const uint64_t progress = c->rayCount * 1024u + c->raysInFlight % 1024u + c->readyForShade.size();
+            if (progress == lastCount) {
+                std::fprintf(stderr, "RayAccelerator watchdog: no progress for %.0f s: moreRaysExist %d raysInFlight %u cpuBusy %u gpuBusy %u | streams %zu: empty %zu, waitingToBeFilled %zu, "
+                                     "readyForTest %zu, readyForShade %zu | traced so far %llu\n", limit, int(c->moreRaysExist), c->raysInFlight, c->cpuBusy, c->gpuBusy, c->streams.size(),
+                             c->empty.size(), c->waitingToBeFilled.size(), c->readyForTest.size(), c->readyForShade.size(), (unsigned long long)c->rayCount);
+                std::abort();
+            }
+            lastCount = progress;
+        }
+    } else {
+        c->wake.wait(lock, done);
+    }
     Stats stats{};
     stats.raysTraced = c->rayCount;
     c->rayCount = 0;

@@ -128,3 +128,20 @@ def test_null_callbacks_scheduler_rate(tmp_path, small_scene):
         info = json.loads(p.stdout.strip().splitlines()[-1])
         assert info["raysTraced"] == info["consumed"] == 8 * 4 * 16384 * 3
         assert info["mrays_per_s_best"] > 5.0
+
+
+def test_fast_callbacks_cannot_starve_the_shading_of_output_streams(tmp_path, full):
+    """Round 5: with callbacks that cost nothing the scheduler deadlocked about once in eight frames-sets — every ray stream had been flushed
+    to the GPU partly filled, came back traced, and no stream was left to shade INTO (shade needs an output stream, reference
+    RayAccelerator.cpp:108; the reference's stream count only covers streams that leave the fill lists full).  The flush now leaves the
+    emptiest streams behind (racc_api.cpp, gpuWorker).  Stream batch of 262,144 rays / six submission threads at 1080p were the
+    configurations that hung; several runs each, under the frame watchdog (a hang aborts with the scheduler's state instead of timing out)."""
+    scene_file = os.path.join(str(tmp_path), "scene.bin")
+    synth.write_scene_bin(scene_file, full["sc"], viewport=(1920, 1080))
+    for cfg in (dict(RACC_BATCH="262144"), dict(RACC_GPU_THREADS="6")):
+        for run in range(6):
+            p = subprocess.run([BIN, scene_file, "--null-callbacks", "1920", "1080", "16", "4"], capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, RACC_CPU_THREADS="16", RACC_RENDER_WATCHDOG_S="5", **cfg))
+            assert p.returncode == 0, "%s run %d: %s" % (cfg, run, (p.stdout + p.stderr)[-1500:])
+            info = json.loads(p.stdout.strip().splitlines()[-1])
+            assert info["raysTraced"] == info["consumed"] == 15 * 8 * 16384 * 16
