@@ -345,7 +345,7 @@ class TreeOptimizer {
 public:
     TreeOptimizer(Bvh2Node* nodes, uint32_t count) : n_(nodes), count_(count) {}
 
-    struct Phase { uint32_t cut; int passes; float fraction; };      // cut 0 = the whole tree (sequential)
+    struct Phase { uint32_t cut; int passes; float fraction; size_t maxCandidates = 0; };      // cut 0 = the whole tree (sequential); maxCandidates 0 = no cap
 
     // returns the index of the root after optimisation
     uint32_t run(const std::vector<Phase>& phases, unsigned threads) {
@@ -353,7 +353,7 @@ public:
         std::vector<uint32_t> leaves(count_, 0);
         for (const Phase& ph : phases) {
             if (ph.passes <= 0) continue;
-            if (ph.cut == 0) { Sub s(n_, root); s.optimise(ph.passes, ph.fraction); root = s.root; continue; }
+            if (ph.cut == 0) { Sub s(n_, root); s.optimise(ph.passes, ph.fraction, ph.maxCandidates); root = s.root; continue; }
             // leaves below every node (iterative post-order: the tree may be deep after earlier phases)
             countLeaves(root, leaves);
             std::vector<uint32_t> roots, stack(1, root);
@@ -363,14 +363,14 @@ public:
                 if (leaves[i] <= ph.cut) { roots.push_back(i); continue; }
                 stack.push_back(n_[i].last); stack.push_back(n_[i].first);
             }
-            if (roots.size() == 1 && roots[0] == root) { Sub s(n_, root); s.optimise(ph.passes, ph.fraction); root = s.root; continue; }
+            if (roots.size() == 1 && roots[0] == root) { Sub s(n_, root); s.optimise(ph.passes, ph.fraction, ph.maxCandidates); root = s.root; continue; }
             std::atomic<size_t> next{0};
             auto work = [&]() {
                 for (;;) {
                     const size_t k = next.fetch_add(1);
                     if (k >= roots.size()) return;
                     Sub s(n_, roots[k]);
-                    s.optimise(ph.passes, ph.fraction);
+                    s.optimise(ph.passes, ph.fraction, ph.maxCandidates);
                 }
             };
             std::vector<std::thread> pool;
@@ -494,7 +494,7 @@ private:
             insert(R, N);
         }
 
-        void optimise(int passes, float fraction) {
+        void optimise(int passes, float fraction, size_t maxCandidates) {
             for (int pass = 0; pass < passes; ++pass) {
                 cand.clear();
                 stack.assign(1, root);
@@ -510,6 +510,7 @@ private:
                 if (cand.empty()) return;
                 size_t k = size_t(double(cand.size()) * double(fraction));
                 k = std::min(std::max<size_t>(k, 1), cand.size());
+                if (maxCandidates && k > maxCandidates) k = maxCandidates;
                 std::partial_sort(cand.begin(), cand.begin() + k, cand.end(),
                                   [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
                 for (size_t j = 0; j < k; ++j) reinsert(cand[j].second);
@@ -703,18 +704,22 @@ void improveTree(racc_host_scene& s, const float* vertices, const uint32_t* indi
     LeafSplitter(s.bvh, s.triangles, vertices, indices).run();
     const auto t1 = std::chrono::steady_clock::now();
     std::vector<TreeOptimizer::Phase> phases;
-    if (const char* e = std::getenv("RACC_BUILD_TUNE")) {
+    const char* tune = std::getenv("RACC_BUILD_TUNE");
+    if (tune && *tune) {
+        const char* e = tune;
         for (const char* p = e; *p;) {
             unsigned cut = 0; int passes = 0; float fraction = 0.0f; int used = 0;
             if (std::sscanf(p, "%u:%d:%f%n", &cut, &passes, &fraction, &used) < 3) break;
-            phases.push_back({cut, passes, fraction});
+            phases.push_back({cut, passes, fraction, 0});
             p += used;
             if (*p == ',') ++p;
         }
     } else if (quality == 1) {
-        phases = {{1024u, 6, 0.10f}, {32768u, 6, 0.05f}, {0u, 3, 0.005f}};
+        // (battlefield-synth, first-bounce rays: 45.2 visits per ray, as many as quality 2's passes to convergence; more or larger passes: 45.3-45.6.  The sequential
+        //  whole-tree passes are capped at 20,000 candidates each: a 25 M-triangle scene would otherwise spend most of its build in them)
+        phases = {{2048u, 3, 0.15f, 0}, {131072u, 4, 0.08f, 0}, {0u, 3, 0.01f, 20000}};
     } else {
-        phases = {{1024u, 10, 0.10f}, {65536u, 10, 0.10f}, {0u, 10, 0.05f}};
+        phases = {{1024u, 10, 0.10f, 0}, {65536u, 10, 0.10f, 0}, {0u, 10, 0.05f, 0}};
     }
     TreeOptimizer opt(s.bvh.data(), uint32_t(s.bvh.size()));
     const double before = prof ? opt.cost(0) : 0.0;
