@@ -80,7 +80,14 @@ typedef struct racc_hip_options {
                                   issued, so a sequence of batches runs like one long launch (no drain between them).  A batch's
                                   arrays belong to the engine until racc_hip_wait on its lane has returned and may be re-issued
                                   at once after that (the exact rule: racc_hip_intersect_device below).  2 => off: every launch
-                                  stands alone, the lanes' launches merely overlap (same rule) */
+                                  stands alone, the lanes' launches merely overlap (same rule).  Round 5: the chain is LAZY — once
+                                  a chain has its kernels (one per lane in rotation), a further batch is only published to them (a
+                                  descriptor written by a one-thread kernel): no traversal kernel that would find nothing left, no
+                                  miss-shading kernel (the chained kernels sample the probe image in their epilogue).  racc_hip_wait /
+                                  racc_hip_synchronize establish completion — the chain's kernels have ended and every published
+                                  batch's rays were handed out — and trace whatever the chain did not reach (it had ended before the
+                                  batch was linked) with a catch-up kernel; hence results are defined, as before, when the wait
+                                  returns.  3 => round 4's form: every chained launch brings its own kernel + miss-shading kernel */
     uint32_t chain_min_rays;   /* only batches of at least this many rays are chained; smaller ones are launched stand-alone on their
                                   lane (they overlap like any two lanes' launches).  A chained launch costs the host more stream
                                   operations, and a batch that is worked off before its successor is linked breaks the chain: 27,648-ray

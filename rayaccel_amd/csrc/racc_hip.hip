@@ -163,7 +163,21 @@ struct racc_hip_ctx {
     uint32_t* chainCursors = nullptr;    // device: kChainRing x 16 words (cursor at word 0), all zero between ring laps
     uint32_t chainHead = 0;              // launches so far
     std::mutex chainMutex;
-    struct { const racc_hip_scene* scene = nullptr; const racc_hip_env* env = nullptr; const void* kernel = nullptr; uint32_t idx = 0; Lane* lane = nullptr; bool valid = false; } chainLast;
+    struct { const racc_hip_scene* scene = nullptr; const racc_hip_env* env = nullptr; const void* kernel = nullptr; uint32_t idx = 0; Lane* lane = nullptr; bool valid = false; bool lazy = false; } chainLast;
+    // Lazy chain (round 5, the default; racc_hip_options::chain_launches = 3 restores "every launch brings its own kernel"): a chained launch
+    // whose chain already has its kernels (one per lane in rotation) only PUBLISHES its descriptor — no kernel that would find nothing
+    // left, no miss-shading kernel (the chained kernels sample the probe image in their own epilogue), no cross-stream waits.  Completion is
+    // established when somebody waits (finishChain): every chain kernel has ended and every published batch's cursor has passed its count;
+    // a batch the chain did not reach (its kernels ended before the link landed) gets a catch-up kernel there.
+    bool chainLazy = true;
+    struct ChainLive { hipEvent_t end; uint32_t chainId; };
+    std::vector<ChainLive> chainLive;    // chain kernels launched and not yet seen ended
+    std::vector<hipEvent_t> chainEventPool;
+    uint32_t chainId = 0;                // bumped at every chain start (a launch with no predecessor to link behind)
+    struct ChainHostDesc { const void* rays; void* results; uint32_t count; const racc_hip_scene* scene; const racc_hip_env* env; const void* variant; uint32_t chunk; };
+    ChainHostDesc chainHost[kChainRing];
+    std::vector<uint32_t> chainOutstanding;      // ring slots published since the last finishChain
+    Lane chainLane;                      // stream + spill area of the catch-up kernels (finishChainLocked)
     bool chainEnabled = true;            // RACC_CHAIN=0 switches it off
     uint32_t chainMinRays = 3u << 18;    // (786,432) smaller batches are launched stand-alone (launchTraverse); RACC_CHAIN_MIN overrides
     hipStream_t pipeIn = nullptr, pipeOut = nullptr;      // host-buffer path: ONE copy-in and ONE copy-out stream per context (racc_hostpath.inc), created on first use
@@ -293,6 +307,8 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
     {
         ctx->chainEnabled = ctx->opts.chain_launches != 2u;
         if (const char* c = std::getenv("RACC_CHAIN")) ctx->chainEnabled = std::atoi(c) != 0;
+        ctx->chainLazy = ctx->opts.chain_launches != 3u;
+        if (const char* c = std::getenv("RACC_CHAIN_LAZY")) ctx->chainLazy = std::atoi(c) != 0;
         if (const char* c = std::getenv("RACC_RAY_SCOPE")) ctx->raysBypassL1 = std::atoi(c) != 0;
         if (ctx->opts.chain_min_rays) ctx->chainMinRays = ctx->opts.chain_min_rays;
         if (const char* c = std::getenv("RACC_CHAIN_MIN")) ctx->chainMinRays = uint32_t(std::atoll(c));
@@ -310,6 +326,7 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
         // them: chunks handed out twice, the second time after the batch's miss shading had run (tests/test_gpu_parity.py::
         // test_chained_launches, launch 1 of a fresh context: a prefix of the batch left with unshaded miss records — seen in 4 of 10
         // runs of the suite once the timing had shifted, never in isolation).  Everything the context zeroes is complete here.
+        if (e1 == hipSuccess) e1 = initLane(ctx->chainLane, false);
         if (e1 == hipSuccess) e1 = hipStreamSynchronize(nullptr);
         if (e1 != hipSuccess) { racc_hip_destroy(ctx); return fail(RACC_HIP_ERR_DEVICE, "chain ring", e1); }
     }
@@ -326,6 +343,9 @@ int racc_hip_destroy(racc_hip_ctx* ctx) {
     if (ctx->chainStream) hipStreamDestroy(ctx->chainStream);
     if (ctx->chainCursors) hipFree(ctx->chainCursors);
     for (Lane& l : ctx->lanes) freeLane(l);
+    freeLane(ctx->chainLane);
+    for (const racc_hip_ctx::ChainLive& l : ctx->chainLive) hipEventDestroy(l.end);
+    for (hipEvent_t ev : ctx->chainEventPool) hipEventDestroy(ev);
     if (ctx->pipeIn) hipStreamDestroy(ctx->pipeIn);
     if (ctx->pipeOut) hipStreamDestroy(ctx->pipeOut);
     delete ctx;
@@ -644,6 +664,7 @@ int racc_hip_synchronize(racc_hip_ctx* ctx) {
     if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    if (int rc = finishChain(ctx)) return rc;      // (lazy chain: a published batch the chain did not reach is traced now)
     for (uint32_t i = 0; i < ctx->opts.lanes; ++i) {
         ctx->lanes[i].launchPending.store(false, std::memory_order_release);
         for (Lane* h : ctx->lanes[i].helper) if (h) h->launchPending.store(false, std::memory_order_release);

@@ -6,7 +6,7 @@ import numpy as np
 import rayaccel_amd as ra
 from rayaccel_amd import synth
 sc = synth.battlefield_synth_xl()
-host = ra.HostScene(sc["vertices"], sc["indices"])
+host = ra.HostScene(sc["vertices"], sc["indices"], quality=int(os.environ.get("RACC_SWEEP_QUALITY", "1")))
 rays = synth.random_rays(1 << 20, 7)
 base = None
 for arg in sys.argv[1:] or ["{}"]:
