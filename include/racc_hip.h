@@ -66,8 +66,13 @@ typedef struct racc_hip_options {
                                   0 => default (20), > 100 => never, 100 => always */
     uint32_t time_kernels;     /* != 0: an event pair around every traversal kernel (racc_hip_read_kernel_times); costs two
                                   hipEventRecord per launch, so off by default */
-    uint32_t drain_prefetch;   /* 1: thin waves of an exhausted batch touch both children's records as soon as a node's child refs
-                                  arrive (measured: -3 % on a 64k-ray batch, +4..10 % on 256k..1M rays); 0 => default (off) */
+    uint32_t drain_prefetch;   /* what a thin wave (few live rays: a launch's drain, a small launch) does about the latency of its node
+                                  fetches.  0 => default: nothing.  1: touch both children's records as soon as the child refs arrive
+                                  (round 2: -3 % on a 64k-ray batch, +4..10 % on 256k..1M rays).  3: every step also requests the record
+                                  BEHIND each lane's node — its likeliest next node in the device order, 46 % of the visits — into the
+                                  lane's LDS-DMA slots, and a lane that goes on into that record reads it from LDS (round 5, built at
+                                  the round-4 verdict's request; measured slower: 64k rays 0.130 vs 0.113-0.116 ms, 1M 0.345 vs 0.320 —
+                                  a wave steps in lockstep, one lane's miss costs the whole step).  Same results in all forms */
     uint32_t leaf_step;        /* 0/1 => the leaf step runs inside the kernel's assembly block and takes the inner lanes' step along
                                   (one memory round trip for both); 2 => in C++ through the block's LEAF door; 3 => in the block,
                                   not fused (A/B; same results) */

@@ -8,7 +8,7 @@ from rayaccel_amd import synth
 from oracle import oracle as orc
 
 sc = synth.battlefield_synth()
-host = ra.HostScene(sc["vertices"], sc["indices"])
+host = ra.HostScene(sc["vertices"], sc["indices"], quality=int(os.environ.get("RACC_SWEEP_QUALITY", "1")))
 prim, _ = synth.primary_rays(sc["camera"], 1024, 1024)
 ref = orc.traverse(host.blobs(), prim, threads=16)
 diff = np.concatenate([synth.diffuse_bounce_rays(sc, prim, ref, 1 << 20, first_sample=s) for s in range(2)])

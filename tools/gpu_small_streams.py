@@ -11,7 +11,7 @@ from oracle import oracle as orc
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 27648
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 sc = synth.battlefield_synth()
-host = ra.HostScene(sc["vertices"], sc["indices"])
+host = ra.HostScene(sc["vertices"], sc["indices"], quality=int(os.environ.get("RACC_SWEEP_QUALITY", "1")))
 prim, _ = synth.primary_rays(sc["camera"], 1024, 1024)
 ref0 = orc.traverse(host.blobs(), prim, threads=16)
 pool = np.ascontiguousarray(synth.diffuse_bounce_rays(sc, prim, ref0, 1 << 21))
