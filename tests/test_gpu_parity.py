@@ -185,7 +185,7 @@ def test_launch_options_do_not_change_results(small_scene, small_host, small):
     ref = orc.traverse(small["blobs"], rays, env=small_scene["env"])
     for opt in (dict(waves_per_simd=1, refill_min=1, leaf_min=1, chunk=1), dict(waves_per_simd=8, refill_min=64, leaf_min=64, chunk=4096),
                 dict(waves_per_simd=3, refill_min=20, leaf_min=7, chunk=100), dict(lanes=1, chunk=64),
-                *[dict(kernel_variant=v) for v in ra.engine.available_variants()], *([dict(kernel_variant=18, regroup_period=3)] if 18 in ra.engine.available_variants() else []), dict(tail_active=65), dict(coop_same_pct=100), dict(coop_same_pct=101), dict(kernel_variant=41, coop_same_pct=100, refill_min=5, leaf_min=3, inner_reps=7), dict(leaf_step=2), dict(leaf_step=3), dict(leaf_step=2, kernel_variant=41), dict(drain_prefetch=1),
+                *[dict(kernel_variant=v) for v in ra.engine.available_variants()], *([dict(kernel_variant=18, regroup_period=3)] if 18 in ra.engine.available_variants() else []), dict(tail_active=65), dict(coop_same_pct=100), dict(coop_same_pct=101), dict(kernel_variant=41, coop_same_pct=100, refill_min=5, leaf_min=3, inner_reps=7), dict(leaf_step=2), dict(leaf_step=3), dict(leaf_step=2, kernel_variant=41), dict(drain_prefetch=1), dict(drain_prefetch=3), dict(drain_prefetch=3, tail_active=64, thin_reps=3), dict(drain_prefetch=3, kernel_variant=41, coop_same_pct=101),
                 dict(kernel_variant=45, leaf_min=1, inner_reps=1, thin_reps=1), dict(kernel_variant=45, leaf_step=3, refill_min=5, chunk=7), dict(kernel_variant=49, leaf_min=3, inner_reps=7, tail_active=65),
                 dict(kernel_variant=50, leaf_min=1, inner_reps=1, thin_reps=1), dict(kernel_variant=50, leaf_step=3, refill_min=5, chunk=7), dict(kernel_variant=53, leaf_min=3, inner_reps=7, tail_active=65), dict(kernel_variant=50, coop_same_pct=101), dict(kernel_variant=53, coop_same_pct=100),
                 dict(chunk=1 << 30), dict(thin_reps=1, inner_reps=1), dict(thin_reps=3, tail_active=40, inner_reps=2), dict(thin_reps=64, tail_active=64), dict(inner_reps=16)):

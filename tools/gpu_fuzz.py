@@ -25,7 +25,7 @@ for rnd in range(rounds):
     if rng.random() < 0.6:
         opt.update(waves_per_simd=int(rng.integers(1, 9)), refill_min=int(rng.integers(1, 65)), leaf_min=int(rng.integers(1, 65)),
                    chunk=int(rng.choice([1, 7, 32, 64, 100, 128, 1000])), tail_active=int(rng.integers(1, 70)),
-                   thin_reps=int(rng.integers(1, 20)), inner_reps=int(rng.integers(1, 9)), coop_same_pct=int(rng.choice([0, 1, 25, 100, 101])), leaf_step=int(rng.choice([0, 0, 2, 3])), drain_prefetch=int(rng.choice([0, 1])))
+                   thin_reps=int(rng.integers(1, 20)), inner_reps=int(rng.integers(1, 9)), coop_same_pct=int(rng.choice([0, 1, 25, 100, 101])), leaf_step=int(rng.choice([0, 0, 2, 3])), drain_prefetch=int(rng.choice([0, 1, 3])))
     with ra.Context(device=0, **opt) as ctx:
         scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
         env = ctx.create_environment(sc["env"])
