@@ -17,7 +17,7 @@
 //   * launches of different lanes (HIP stream + ray cursor + spill area each) overlap: one's drain runs beside the next
 //     one's bulk.
 // The shipped kernel, traverseKernelV8 (hot loop in hand-scheduled assembly), is in racc_kernel_v8.inc; the seven earlier
-// generations are in tools/experimental/racc_kernels_experimental.inc and exist only in a `make EXPERIMENTAL=1` build.
+// generations (V1-V7, kernel_variant 1-40) left the tree in round 5: `git log -- tools/experimental/`.
 // Arithmetic is IEEE binary32 with explicit fmaf only (built with -ffp-contract=off, no fast-math), the same evaluation
 // order as oracle/racc_oracle.c, so primId/t/u/v are bit-identical to the CPU restatement for every finite ray.  The
 // traversal ORDER is the reference's (nearer child first, far child pushed only if both hit, pairs of a leaf in order),
@@ -60,10 +60,6 @@ namespace {
 #include "racc_kernel_v9.inc"
 
 #include "racc_kernel_v10.inc"
-
-#ifdef RACC_EXPERIMENTAL
-#include "racc_kernels_experimental.inc"      // V1..V7: earlier generations and ablations, tools/experimental/, `make EXPERIMENTAL=1`
-#endif
 
 // ------------------------------------------------------------------------------------------ host side
 
@@ -214,11 +210,7 @@ namespace {
 
 extern "C" {
 
-#ifdef RACC_EXPERIMENTAL
-const char* racc_hip_version(void) { return "racc-hip 0.2 (gfx950, experimental kernels included)"; }
-#else
 const char* racc_hip_version(void) { return "racc-hip 0.2 (gfx950)"; }
-#endif
 
 int racc_hip_lane_count(const racc_hip_ctx* ctx, uint32_t* lanes, uint32_t* auto_lanes) {
     if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
@@ -267,7 +259,7 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
     ctx->opts.struct_size = sizeof(racc_hip_options);
     if (ctx->opts.kernel_variant && !variantById(ctx->opts.kernel_variant)) {
         delete ctx;
-        return fail(RACC_HIP_ERR_INVALID, "kernel_variant is not in this build (experimental kernels: make EXPERIMENTAL=1)");
+        return fail(RACC_HIP_ERR_INVALID, "kernel_variant is not in this build (the earlier kernel generations left the tree in round 5: git history, tools/experimental/)");
     }
     // How many launches to keep in flight.  HIP streams share hardware queues (GPU_MAX_HW_QUEUES, 4 unless the environment says
     // otherwise), and kernels of two streams on one hardware queue do not overlap.  Measured on 1M-ray diffuse batches back to

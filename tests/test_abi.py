@@ -79,15 +79,14 @@ def test_consumer_libraries_load_and_export_their_entry_points():
         assert "libracc_hip.so" in out and "oracle" not in out and "torch" not in out
 
 
-def test_shipped_build_has_the_v8_kernels_only():
-    """racc_hip_variant_available needs no GPU: 0 (default) and the V8 rows exist in every build; the earlier generations
-    (rows 1-40) only in a `make EXPERIMENTAL=1` build, which the version string then says."""
+def test_build_has_the_current_kernels_only():
+    """racc_hip_variant_available needs no GPU: 0 (default) and the V8 / V9 / V10 rows exist; the earlier generations (rows 1-40, retired
+    from the tree in round 5) do not."""
     import rayaccel_amd as ra
     lib = ra.load_library()
     assert lib.racc_hip_variant_available(0) == 1 and lib.racc_hip_variant_available(41) == 1 and lib.racc_hip_variant_available(43) == 1
-    assert lib.racc_hip_variant_available(1000) == 0
-    experimental = b"experimental" in lib.racc_hip_version()
-    assert bool(lib.racc_hip_variant_available(22)) == experimental
+    assert lib.racc_hip_variant_available(1000) == 0 and lib.racc_hip_variant_available(22) == 0
+    assert b"experimental" not in lib.racc_hip_version()
     assert ra.engine.Options.__dict__ is not None and __import__("ctypes").sizeof(ra.engine.Options) == 72      # the options block is ABI: 18 words (struct_size tells older callers apart)
 
 

@@ -683,8 +683,8 @@ def test_api_misuse_is_reported_not_fatal(gpu_ctx, small):
         ra.Context(device=0, kernel_variant=1000)
     if 22 not in ra.engine.available_variants():
         with pytest.raises(ra.RaccError) as e:
-            ra.Context(device=0, kernel_variant=22)              # an experimental kernel in a shipped build
-        assert "EXPERIMENTAL" in str(e.value)
+            ra.Context(device=0, kernel_variant=22)              # a retired kernel generation
+        assert "not in this build" in str(e.value)
     with pytest.raises(ra.RaccError):
         ra.Comm(gpu_ctx, ra.Comm.unique_id(), 3, 2)              # rank outside the world
     with pytest.raises(ra.RaccError):
