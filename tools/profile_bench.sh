@@ -7,7 +7,7 @@
 #   stats_one_lane[_X]    the same with one lane and no chaining (every kernel alone, one batch each); X = coherent: configs[1]'s batch; v10: kernel_variant 50
 #   pmc_<i>               one counter set per pass, diffuse batch, one lane, no chaining: counters describe ONE launch of ONE batch alone on the GPU
 #   pmcc_<i>              the same for the coherent primary batch (--workload coherent), fewer sets
-#   pmcv_<i>              the same for the compressed 4-wide kernel (kernel_variant 50), diffuse batch, fewer sets
+#   (the compressed 4-wide kernel, kernel_variant 50, has not changed since round 4: its passes are profiles/r04's)
 #   pmcx_<i>              FETCH_SIZE / WRITE_SIZE in the timed region's own mode (three lanes, chained); rocprofv3 serialises dispatches under --pmc
 #   stats_one_lane_q0, pmcq_<i>, stats_one_lane_xl_q0, pmcxq_<i>   the reference builder's tree (--quality 0; every other pass runs bench.py's default, quality 1)
 #   pmcxl_<i>, pmcxd_<i>  battlefield-synth-XL (1.3 GB on the device: past the Infinity Cache), 1M incoherent rays / the camera's 1M diffuse rays, one lane, no chaining
@@ -25,7 +25,6 @@ V10='{"lanes":1,"chain_launches":2,"kernel_variant":50}'
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_lane" -- $CMD --engine-opts "$ONE" > "$OUT/stats_one_lane.log" 2>&1
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_lane_coherent" -- $CMD --workload coherent --engine-opts "$ONE" > "$OUT/stats_one_lane_coherent.log" 2>&1
-timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_lane_v10" -- $CMD --engine-opts "$V10" > "$OUT/stats_one_lane_v10.log" 2>&1
 pass() {   # pass <dir prefix> <index> "<counters>" <extra bench args...>
   local pre=$1 i=$2 set=$3; shift 3
   timeout -k 5 240 rocprofv3 --pmc $set --output-format csv -d "$OUT/${pre}_$i" -- $CMD "$@" > "$OUT/${pre}_$i.log" 2>&1 || echo "pass ${pre}_$i ($set) failed"
@@ -42,7 +41,6 @@ i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY" "GRBM_GUI_ACTIVE GRBM_COUNT" "TA_TA_BUSY_sum TD_TD_BUSY_sum"; do
   i=$((i+1)); pass pmcc $i "$set" --workload coherent --engine-opts "$ONE"
-  pass pmcv $i "$set" --engine-opts "$V10"
 done
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
@@ -62,18 +60,17 @@ passxl() {   # the XL scene takes ~20 s to build: its own, longer timeout
   timeout -k 5 400 rocprofv3 --pmc $set --output-format csv -d "$OUT/${pre}_$i" -- $CMD "$@" > "$OUT/${pre}_$i.log" 2>&1 || echo "pass ${pre}_$i ($set) failed"
 }
 i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
-           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY" \
-           "GRBM_GUI_ACTIVE GRBM_COUNT" "TA_TA_BUSY_sum TD_TD_BUSY_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" \
+           "GRBM_GUI_ACTIVE GRBM_COUNT" "TA_TA_BUSY_sum TD_TD_BUSY_sum"; do
   i=$((i+1)); passxl pmcxl $i "$set" --workload xl --engine-opts "$ONE"
 done
 i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE GRBM_COUNT" "TA_TA_BUSY_sum TD_TD_BUSY_sum"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1)); passxl pmcxd $i "$set" --workload xl_diffuse --engine-opts "$ONE"
 done
 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_lane_xl_q0" -- $CMD --workload xl --quality 0 --engine-opts "$ONE" > "$OUT/stats_one_lane_xl_q0.log" 2>&1
 i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "GRBM_GUI_ACTIVE GRBM_COUNT" "TA_TA_BUSY_sum TD_TD_BUSY_sum"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1)); passxl pmcxq $i "$set" --workload xl --quality 0 --engine-opts "$ONE"
 done
 find "$OUT" -name "*.csv" | wc -l
