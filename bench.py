@@ -659,15 +659,17 @@ def main():
                     "hbm": {"peak_gbs": HBM_PEAK_GBS, "fabric_traffic_frac_of_peak": c.get("fabric_frac_of_hbm_peak"),
                             "traffic_frac_of_algorithmic": round(traffic / alg_bytes, 4) if traffic else None}},
                 "traffic_what": "L2-miss / fabric bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes, gfx950 correction of the guide), "
-                                "the kernel alone on the GPU as for `achieved`; includes Infinity-Cache hits, so an upper bound of HBM traffic; %s/pmc_summary.json" % PROFILE_DIR,
+                                "the kernel alone on the GPU as for `achieved`; includes Infinity-Cache hits, so an upper bound of HBM traffic; %s/pmc_summary.json.  The x 2 is calibrated for "
+                                "this access pattern: a gather of 64-byte records through the kernel's own fetch moves whole 128-byte lines, each tallied at 64 B (%s/fetchcal.json)" % (PROFILE_DIR, PROFILE_DIR),
                 # the timed region: launches are chained and overlap, so the rate is bytes per launch over the time the region spends per launch
                 "timed_region": None if not alg_bytes else {
                     "ms_per_step": round(step_s * 1e3, 4), "algorithmic_gbs": round(alg_step / step_s / 1e9, 1),
                     "x_hbm_peak": round(alg_step / step_s / 1e9 / HBM_PEAK_GBS, 4),
                     "ray_batches_in_rotation": len(d_sets), "algorithmic_bytes_per_step_mean": int(alg_step),
                     "kernel_event_ms_avg": round(avg_kernel_ms, 4) if avg_kernel_ms else None,
-                    "kernel_event_note": "HIP events around every traversal kernel of the timed region: chained launches — the first kernels of a sequence work "
-                                         "through the later batches, whose own kernels then find nothing left — so this is not a per-launch duration",
+                    "kernel_event_note": "only with --engine-opts '{\"time_kernels\":1}': HIP events around every traversal kernel of the timed region.  Launches are chained "
+                                         "lazily: the chain's first kernels (one per lane in rotation) work through all K batches, the later batches are only "
+                                         "published to them — so no per-launch duration exists in the timed region; `roofline.kernel_ms_avg` is the isolated one",
                     "fabric_bytes_per_step_chained": pw.get("fabric_bytes_per_step_chained")},
                 "limiter": None if not pw else {k: pw.get(k) for k in (
                     "bound", "td_busy_frac", "ta_busy_frac", "valu_busy_frac", "valu_lane_util", "salu_share",

@@ -18,3 +18,5 @@ for f in ("bench_r05_k20", "bench_r05_default", "bench_r05_k20_q0"):
     except Exception as e:
         print(f, "failed", e)
 PY
+# how often does the suite's chained-launch test exercise the lazy chain's catch-up path (a batch the chain did not reach)?
+RACC_CHAIN_LOG=1 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "test_chained_launches" -s 2>&1 | grep -c "catch-up kernel" | sed 's/^/catch-up kernels in test_chained_launches*: /'
