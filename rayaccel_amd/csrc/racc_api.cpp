@@ -68,7 +68,15 @@ struct Context {
     std::vector<uint32_t> empty, waitingToBeFilled, readyForTest, readyForShade;
 
     std::mutex mutex;
-    std::condition_variable wake;
+    // One condition variable per role (round 5).  With a single one every spawn, shade slice and launch woke all twenty threads, which then
+    // queued up on the mutex: with callbacks that cost nothing that convoy was what bounded racc::render (render_check --null-callbacks).
+    // CPU workers all wait for the same thing (a stream to spawn into or to shade), so one resource freed = notify_one on wakeCpu.
+    std::condition_variable wakeCpu, wakeGpu, wakeRender;
+    void wakeEverybody() { wakeCpu.notify_all(); wakeGpu.notify_all(); wakeRender.notify_all(); }
+    uint32_t shadeWaiters = 0;       // CPU workers inside shadeRays waiting for an output stream: they wait for less than the idle workers do
+    // one stream went back into the fill lists: any ONE idle worker can use it as well as another — unless somebody in the middle of a stream
+    // waits for exactly that (then everybody looks: the one notify must not go to a worker that cannot use it)
+    void streamFreed() { if (shadeWaiters) wakeCpu.notify_all(); else wakeCpu.notify_one(); }
     bool shouldExit = false;
     bool moreRaysExist = false;
     uint32_t raysInFlight = 0;
@@ -155,11 +163,15 @@ bool spawnRays(Context* c, std::unique_lock<std::mutex>& lock, unsigned thread) 
     c->raysInFlight -= maxRaysPerSpawn - std::min(added, maxRaysPerSpawn);
     putBack(c, id);
     if (!more) c->moreRaysExist = false;
-    c->wake.notify_all();
+    c->wakeGpu.notify_all();       // a stream may be ready for the GPU; cpuBusy / moreRaysExist feed its flush rule
+    c->streamFreed();              // one stream is back in the fill lists (or a reservation was released): one worker can go on
+    if (!more) c->wakeRender.notify_one();
     return true;
 }
 
-// reference shadeRays, :92-156.
+// reference shadeRays, :92-156.  The output stream is kept across the slices of one input stream (the reference — and rounds 1-4 — took
+// and returned one under the mutex for every slice of cpuShadeBatch rays: 146,000 lock round trips and wake-ups per second at 1.2 Grays/s);
+// it goes back when it has reached a full batch or cannot take another slice, and at the end.
 bool shadeRays(Context* c, std::unique_lock<std::mutex>& lock, unsigned thread) {
     if (c->readyForShade.empty() || (c->waitingToBeFilled.empty() && c->empty.empty())) return false;
     const RenderCallbacks cb = c->currentCallbacks;
@@ -168,27 +180,41 @@ bool shadeRays(Context* c, std::unique_lock<std::mutex>& lock, unsigned thread) 
     c->readyForShade.pop_back();
     RayStream* stream = &c->streams[id];
     ++c->cpuBusy;
-    for (uint32_t start = 0; start < stream->count; start += batch) {
+    uint32_t outId = 0;
+    RayStream* out = nullptr;
+    uint32_t addedSinceLock = 0;
+    for (uint32_t start = 0; start < stream->count; start += batch) {      // (at the top of an iteration the mutex is held iff no output stream is)
         const uint32_t end = std::min(stream->count, start + batch);
-        while (c->waitingToBeFilled.empty() && c->empty.empty()) c->wake.wait(lock);   // never with the reference's stream count
-        const uint32_t outId = takeOutputStream(c);
-        RayStream* out = &c->streams[outId];
-        lock.unlock();
+        if (!out) {
+            ++c->shadeWaiters;
+            while (c->waitingToBeFilled.empty() && c->empty.empty()) c->wakeCpu.wait(lock);   // never with the reference's stream count
+            --c->shadeWaiters;
+            outId = takeOutputStream(c);
+            out = &c->streams[outId];
+            lock.unlock();
+        }
         const uint32_t before = out->count;
         const uint64_t t0 = c->profile ? nowNs() : 0;
         cb.shade(cb.data, thread, stream, start, end, out);
         if (c->profile) c->nsShade += nowNs() - t0;
-        const uint32_t added = out->count - before;
+        addedSinceLock += out->count - before;
+        // go on shading into `out`, without the mutex, while slices are left, it can take another whole one and has not reached a full batch
+        if (end < stream->count && out->count < c->configuration.rayStreamBatchSize && out->count + batch <= c->rayStreamSize) continue;
         lock.lock();
-        c->raysInFlight += added;
+        c->raysInFlight += addedSinceLock;      // (while they were not counted this thread was counted in cpuBusy: render() cannot have finished)
+        addedSinceLock = 0;
         putBack(c, outId);
-        c->wake.notify_all();
+        out = nullptr;
+        c->wakeGpu.notify_all();
+        c->streamFreed();
     }
     c->raysInFlight -= stream->count;
     stream->count = 0;
     c->empty.push_back(id);
     --c->cpuBusy;
-    c->wake.notify_all();
+    c->wakeCpu.notify_all();       // a stream is empty again and rays have left the flight count: several workers may be able to spawn
+    c->wakeGpu.notify_all();       // cpuBusy feeds the flush rule
+    c->wakeRender.notify_one();
     return true;
 }
 
@@ -203,7 +229,7 @@ void cpuWorker(Context* c, unsigned thread) {   // reference cpuWorkerThread (GP
         if (finished(c)) break;
         if (c->currentCallbacks.spawn && spawnRays(c, lock, thread)) continue;
         if (c->currentCallbacks.shade && shadeRays(c, lock, thread)) continue;
-        c->wake.wait(lock);
+        c->wakeCpu.wait(lock);
     }
 }
 
@@ -238,14 +264,14 @@ void gpuWorker(Context* c, unsigned worker) {   // reference gpuWorkerThread, :3
             const size_t keep = std::max<size_t>(1, std::min<size_t>(c->configuration.cpuThreads, c->streams.size() / 4));
             const size_t spare = c->empty.size() >= keep ? 0 : keep - c->empty.size();
             if (spare >= c->waitingToBeFilled.size()) {      // (all of them are needed as outputs: whoever is being traced or shaded now will free streams)
-                c->wake.wait(lock);
+                c->wakeGpu.wait(lock);
                 continue;
             }
             std::sort(c->waitingToBeFilled.begin(), c->waitingToBeFilled.end(), [c](uint32_t a, uint32_t b) { return c->streams[a].count < c->streams[b].count; });
             ids.assign(c->waitingToBeFilled.begin() + spare, c->waitingToBeFilled.end());
             c->waitingToBeFilled.resize(spare);
         } else {
-            c->wake.wait(lock);
+            c->wakeGpu.wait(lock);
             continue;
         }
         rays.clear(); results.clear(); counts.clear();
@@ -285,7 +311,9 @@ void gpuWorker(Context* c, unsigned worker) {   // reference gpuWorkerThread, :3
         } else {
             for (uint32_t id : ids) c->readyForShade.push_back(id);
         }
-        c->wake.notify_all();
+        c->wakeCpu.notify_all();       // several streams to shade (or, after a failure, to spawn into)
+        c->wakeGpu.notify_all();       // (a failure changes moreRaysExist: the flush rule)
+        c->wakeRender.notify_one();
     }
 }
 
@@ -326,7 +354,7 @@ Configuration defaultConfiguration(GpuContext gpuContext) {   // reference :429-
     const unsigned hw = usableCpus();
     cfg.cpuThreads = std::min(hw > 2 ? hw - 2 : 1u, 32u);   // callbacks only; leave room for the submission threads
     cfg.gpuSubmissionThreads = 4 * (gpuContext ? gpuContext->count : 1u);   // per GPU: copy-in, kernel and copy-out of consecutive launches in flight (racc_hostpath.inc; the reference's own default is 4, RayAccelerator.cpp:436)
-    cfg.maxRaysInFlight = 4u << 20;                         // reference 262,144 = 29 x its iGPU's 8,960 lanes; MI355X holds 327,680+
+    cfg.maxRaysInFlight = 8u << 20;                         // reference 262,144 = 29 x its iGPU's 8,960 lanes.  Here a launch spends ~2 ms between spawn and shade (PCIe both ways, four of them in flight): at the link's 1.7 Grays/s that is 3.4 M rays before a stream comes back — 4 M starved the spawners (render_check --null-callbacks: 1.08-1.17 Grays/s, 8 M: 1.21-1.25; 700 MB of page-locked streams)
     cfg.maxRaysPerSpawn = 128 * 128;
     cfg.cpuTestBatch = 1024;
     cfg.cpuShadeBatch = 8 * 1024;
@@ -406,7 +434,7 @@ void destroy(Context* c) {   // reference :761-788
         std::lock_guard<std::mutex> lock(c->mutex);
         c->shouldExit = true;
     }
-    c->wake.notify_all();
+    c->wakeEverybody();
     for (std::thread& t : c->threads) t.join();
     if (c->profile) {
         const double wall = double(c->nsRender.load()) * 1e-9;
@@ -503,13 +531,13 @@ Stats render(Context* c, Scene* scene, Environment* environment, RenderCallbacks
     c->currentEnvironment = environment;
     c->currentCallbacks = callbacks;
     c->moreRaysExist = true;
-    c->wake.notify_all();
+    c->wakeEverybody();
     auto done = [c] { return !c->moreRaysExist && c->raysInFlight == 0 && c->cpuBusy == 0 && c->gpuBusy == 0; };
     // RACC_RENDER_WATCHDOG_S=<seconds> (diagnostics): a frame that makes no progress for that long prints the scheduler's state and aborts
     static const double limit = [] { const char* e = std::getenv("RACC_RENDER_WATCHDOG_S"); return e ? std::atof(e) : 0.0; }();
     if (limit > 0.0) {
         uint64_t lastCount = ~0ull;
-        while (!c->wake.wait_for(lock, std::chrono::duration<double>(limit), done)) {
+        while (!c->wakeRender.wait_for(lock, std::chrono::duration<double>(limit), done)) {
             const uint64_t progress = c->rayCount * 1024u + c->raysInFlight % 1024u + c->readyForShade.size();
             if (progress == lastCount) {
                 std::fprintf(stderr, "RayAccelerator watchdog: no progress for %.0f s: moreRaysExist %d raysInFlight %u cpuBusy %u gpuBusy %u | streams %zu: empty %zu, waitingToBeFilled %zu, "
@@ -520,7 +548,7 @@ Stats render(Context* c, Scene* scene, Environment* environment, RenderCallbacks
             lastCount = progress;
         }
     } else {
-        c->wake.wait(lock, done);
+        c->wakeRender.wait(lock, done);
     }
     Stats stats{};
     stats.raysTraced = c->rayCount;
