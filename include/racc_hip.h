@@ -51,8 +51,10 @@ typedef struct racc_hip_options {
                                   8 bits — half the node bytes and vector-memory instructions per ray; 4-8 % faster on incoherent
                                   batches; same closest hit except exact-distance ties and hits the reference's own box test drops
                                   although its pair test accepts them: there the CLOSER hit, confirmed by the double-precision
-                                  arbiter, is reported); 45 => the uncompressed 4-wide kernel (V9, 128-byte nodes); others:
-                                  DESIGN.md §3, racc_hip_variant_available */
+                                  arbiter, is reported); 45 => the uncompressed 4-wide kernel (V9, 128-byte nodes); 60-63 => the
+                                  default kernel with the top of the tree (524 / 768 / 260 / 128 node records) held in LDS, 16
+                                  waves per CU as workgroups of 1024 / 1024 / 512 / 256 threads: bit-identical results, measured
+                                  slower, kept for the A/B; others: DESIGN.md §3, racc_hip_variant_available */
     uint32_t refill_min;       /* idle lanes that trigger a wave refill; 0 => default */
     uint32_t leaf_min;         /* leaf-holding lanes that trigger a leaf step; 0 => default */
     uint32_t chunk;            /* rays a wave dequeues per cursor atomic; 0 => default */
@@ -364,6 +366,8 @@ int racc_host_scene_bvh2(const racc_host_scene* scene,
  * box — a ray that goes on into that child finds its record in the line it has just fetched — lines in depth-first order; nodes whose
  * children are both leaves share lines pairwise; all-zero padding records (no reference points at them) fill the rest, so *count may
  * exceed node_count.  order 0: the 4096 nodes with the largest boxes first, the rest in the blob's order (round 1-3 layout).
+ * order > 1 (what a context created with kernel_variant 60-63 uploads): the `order` nodes with the largest own boxes first — a
+ * connected top of the tree, the records those kernels keep in LDS — and the subtrees below them in order 1's line pairs.
  * out64 may be NULL (then only *count is returned); capacity in records. */
 int racc_host_scene_device_nodes(const void* nodes64, uint32_t node_count, uint32_t pair_count, uint32_t remap_count, int order,
                                  void* out64, uint32_t capacity, uint32_t* count);

@@ -357,10 +357,10 @@ int racc_hip_scene_upload(racc_hip_ctx* ctx, const void* nodes64, uint32_t node_
     if (!s) return fail(RACC_HIP_ERR_NOMEM, "out of host memory");
     const size_t pb = size_t(pair_count) * 48, rb = size_t(remap_count) * 4;
     const Variant& own = pickVariant(ctx, info.inner_height);
-    int order = own.cacheNodes > 0 ? 0 : 1;      // (kernels with an LDS node cache — experimental builds — want the largest boxes first)
-    if (const char* o = std::getenv("RACC_NODE_ORDER")) order = std::atoi(o) == 0 ? 0 : 1;
+    int order = own.cacheNodes > 0 ? 2 : 1;      // (kernels with an LDS node cache want the largest boxes first)
+    if (const char* o = std::getenv("RACC_NODE_ORDER")) order = std::atoi(o) == 0 ? 0 : (std::atoi(o) == 2 ? 2 : 1);
     std::vector<GpuNodeHost> ordered;
-    reorderNodes(static_cast<const GpuNodeHost*>(nodes64), node_count, ordered, order);
+    reorderNodes(static_cast<const GpuNodeHost*>(nodes64), node_count, ordered, order, uint32_t(own.cacheNodes));
     if (ordered.size() > (size_t(1) << 26)) { delete s; return fail(RACC_HIP_ERR_LIMIT, "more than 2^26 device node records"); }
     s->deviceNodes = uint32_t(ordered.size());
     const size_t nb = ordered.size() * 64;
@@ -420,7 +420,7 @@ int racc_host_scene_device_nodes(const void* nodes64, uint32_t node_count, uint3
     racc_hip_scene_info info{};
     if (int rc = validateScene(static_cast<const GpuNodeHost*>(nodes64), node_count, pair_count, remap_count, info)) return rc;
     std::vector<GpuNodeHost> ordered;
-    reorderNodes(static_cast<const GpuNodeHost*>(nodes64), node_count, ordered, order == 0 ? 0 : 1);
+    reorderNodes(static_cast<const GpuNodeHost*>(nodes64), node_count, ordered, order == 0 ? 0 : (order == 1 ? 1 : 2), order > 1 ? uint32_t(order) : 0u);      // order > 1: that many largest-area nodes first (the LDS cache of kernel variants 60-63), line pairs behind them
     *count = uint32_t(ordered.size());
     if (out64) {
         if (capacity < ordered.size()) return fail(RACC_HIP_ERR_INVALID, "device_nodes: capacity too small");

@@ -534,7 +534,7 @@ def test_chained_launches(small_scene, small_host, small):
     ref_other = orc.traverse(other_host.blobs(), pool[:5000], env=small_scene["env"])
     # (chain_min_rays = 1: every batch is chained, whatever its size — the hard case; 0: the default threshold, under which this pool's
     #  batches of <= 130k rays are plain overlapping launches; variant 50: the compressed 4-wide kernel has a chained instantiation too)
-    for chain, variant, chain_min in ((0, 0, 1), (0, 0, 0), (2, 0, 0), (0, 50, 1)):
+    for chain, variant, chain_min in ((0, 0, 1), (0, 0, 0), (2, 0, 0), (0, 50, 1), (0, 60, 1), (3, 62, 1), (0, 63, 1)):      # (60-63: the kernels with an LDS node cache)
         check = assert_same_closest_hit if variant in WIDE_VARIANTS else assert_bit_exact
         with ra.Context(device=0, chain_launches=chain, kernel_variant=variant, chain_min_rays=chain_min) as ctx:
             scene = ctx.upload_scene(small_host.nodes, small_host.pairs, small_host.remap)

@@ -231,6 +231,46 @@ def test_device_node_order_is_the_same_tree(small_scene, small_host, order):
         assert ((area(rows, 0) >= area(rows, 6)) == first_behind).all()
 
 
+@pytest.mark.parametrize("top", [128, 524, 7])
+def test_device_node_order_with_a_cached_top_is_the_same_tree(small_scene, small_host, top):
+    """Order 2 (kernel variants 60-63, whose workgroups hold device records [0, CACHE) in LDS): the `top` nodes with the largest own boxes
+    first — a connected top of the tree, root at 0, areas falling — and the subtrees below it in order 1's line pairs.  Same tree for the
+    oracle bit for bit; asked for as racc_host_scene_device_nodes(order = top)."""
+    dev = small_host.device_nodes(top)
+    n = len(small_host.nodes)
+    inner = lambda r: (r & 0x80000000) != 0
+    used = np.zeros(len(dev), bool)
+    used[0] = True
+    parent = np.full(len(dev), -1, np.int64)
+    for col in (0, 1):
+        rows = np.nonzero(inner(dev[:, col]))[0]
+        idx = dev[rows, col] & 0x7FFFFFFF
+        assert idx.max() < len(dev) and not used[idx].any()
+        used[idx] = True
+        parent[idx] = rows
+    assert used.sum() == n and not dev[~used].any()
+    assert len(dev) - n <= max(3, n // 50)
+    rays = np.concatenate([synth.primary_rays(small_scene["camera"], 96, 96)[0], synth.random_rays(6000, seed=3, ymax=30.0)])
+    a = orc.traverse(small_host.blobs(), rays, env=small_scene["env"])
+    b = orc.traverse(dict(small_host.blobs(), nodes=_device_to_reference(dev)), rays, env=small_scene["env"])
+    assert a.tobytes() == b.tobytes()
+    k = min(top, n)
+    assert used[:k].all() and (parent[1:k] < np.arange(1, k)).all()          # connected: every top node's parent sits before it
+    pl = dev[:, 4:16].view(np.float32).astype(np.float64)
+    own = lambda r: (np.maximum(pl[r, 1:6:2], pl[r, 7:12:2]) - np.minimum(pl[r, 0:6:2], pl[r, 6:12:2]))
+    d = own(np.arange(k))
+    area = d[:, 0] * d[:, 1] + d[:, 0] * d[:, 2] + d[:, 1] * d[:, 2]
+    assert (np.diff(area) <= 1e-9 * area[:-1]).all()                          # largest boxes first
+    rest = np.arange(k, len(dev))
+    d = own(rest[used[rest]])
+    assert (d[:, 0] * d[:, 1] + d[:, 0] * d[:, 2] + d[:, 1] * d[:, 2]).max() <= area[-1] * (1 + 1e-9)      # ... and nothing below the top is larger than its last node
+    start = k + (k & 1)
+    ev = np.arange(start, len(dev) - 1, 2)
+    child_behind = (dev[ev, 0] == (0x80000000 | (ev + 1))) | (dev[ev, 1] == (0x80000000 | (ev + 1)))
+    childless = ~inner(dev[:, 0]) & ~inner(dev[:, 1])
+    assert (child_behind | (childless[ev] & (childless[ev + 1] | ~used[ev + 1]))).all()                      # behind the top: a line = parent + child, or two childless nodes
+
+
 @pytest.mark.parametrize("cfg", [dict(RACC_CPU_THREADS="5", RACC_BATCH="2048", RACC_IN_FLIGHT="60000", RACC_GPU_THREADS="3", RACC_SHADE_BATCH="500"),
                                  dict(RACC_CPU_THREADS="2", RACC_BATCH="16384", RACC_IN_FLIGHT="16384", RACC_GPU_THREADS="4", RACC_DEVICES="0,1"),
                                  dict(RACC_CPU_THREADS="7", RACC_BATCH="700", RACC_IN_FLIGHT="20000", RACC_GPU_THREADS="1", RACC_SHADE_BATCH="64")])
