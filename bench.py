@@ -672,7 +672,7 @@ def main():
                                          "published to them — so no per-launch duration exists in the timed region; `roofline.kernel_ms_avg` is the isolated one",
                     "fabric_bytes_per_step_chained": pw.get("fabric_bytes_per_step_chained")},
                 "limiter": None if not pw else {k: pw.get(k) for k in (
-                    "bound", "td_busy_frac", "ta_busy_frac", "valu_busy_frac", "valu_lane_util", "salu_share",
+                    "bound", "wave_time_split", "td_busy_frac", "ta_busy_frac", "valu_busy_frac", "valu_lane_util", "salu_share",
                     "l2_hit_rate", "vmem_rd_insts_per_ray", "valu_insts_per_ray", "kernel_ms_isolated", "write_x_compulsory")},
                 "profile_source": (prof or {}).get("source"),
                 "profile_stale": bool(prof["stale"]) if prof else None})

@@ -108,9 +108,22 @@ def derive(c, trace, rays=1 << 20):
         if g(k): der[k + "_per_launch"] = g(k)
     if g("TCC_HIT_sum") and g("TCC_MISS_sum"):
         der["l2_hit_rate"] = round(g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")), 4)
+    # Where a wave's lifetime goes (the three states are disjoint and add up to SQ_WAVE_CYCLES: MI355X_MICROARCH.md, SQ counters): parked at an
+    # s_waitcnt / barrier, stalled at issue, executing.  TD_TD_BUSY counts cycles in which the data-return path has a request OUTSTANDING — a
+    # latency measure, not a volume one: taking a third of the L1 accesses away (the LDS node cache, profiles/r05/cache_ab_pmc.json) moves
+    # neither it nor the launch time.
+    if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_ANY") and g("SQ_ACTIVE_INST_ANY") and g("SQ_WAIT_INST_ANY") is not None:
+        wc = g("SQ_WAVE_CYCLES")
+        der["wave_time_split"] = dict(waiting=round(g("SQ_WAIT_ANY") / wc, 4), issue_stalled=round(g("SQ_WAIT_INST_ANY") / wc, 4), executing=round(g("SQ_ACTIVE_INST_ANY") / wc, 4))
     busiest = max(((der.get(k) or 0.0, k) for k in ("td_busy_frac", "ta_busy_frac", "valu_busy_frac")), default=(0, None))
-    names = dict(td_busy_frac="TD (vector-memory data-return path of the CU)", ta_busy_frac="TA (vector-memory address path of the CU)", valu_busy_frac="VALU issue")
-    der["bound"] = "%s: busy %.0f %% of the launch, drain included" % (names.get(busiest[1], "?"), 100 * busiest[0]) if busiest[0] else None
+    names = dict(td_busy_frac="TD (the CU's vector-memory data-return path has a request outstanding)", ta_busy_frac="TA (vector-memory address path of the CU)", valu_busy_frac="VALU issue")
+    if busiest[0]:
+        wts = der.get("wave_time_split")
+        der["bound"] = ("latency of a step's dependent chain at this occupancy: a wave spends %.0f %% of its lifetime parked at a wait, %.0f %% stalled at issue, %.0f %% executing; busiest unit %s: %.0f %% of the launch, drain included"
+                        % (100 * wts["waiting"], 100 * wts["issue_stalled"], 100 * wts["executing"], names.get(busiest[1], "?"), 100 * busiest[0])) if wts else \
+                       "%s: busy %.0f %% of the launch, drain included" % (names.get(busiest[1], "?"), 100 * busiest[0])
+    else:
+        der["bound"] = None
     return der
 
 
@@ -152,6 +165,7 @@ der = dict(kernel_source_sha256=out["kernel_source_sha256"], kernel_v10_source_s
                salu_share="SQ_INSTS_SALU / (SQ_INSTS_VALU + SQ_INSTS_SALU + SQ_INSTS_VMEM_RD + SQ_INSTS_VMEM_WR + SQ_INSTS_LDS + SQ_INSTS_SMEM)",
                l2_hit_rate="TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)",
                vmem_rd_insts_per_ray="SQ_INSTS_VMEM_RD / 2^20 rays (wave-level instructions)",
+               wave_time_split="SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY, each / SQ_WAVE_CYCLES (disjoint states of a resident wave)",
                fabric_bytes_per_step_chained="(2 * sum FETCH_SIZE + sum WRITE_SIZE) * 1024 over the traversal dispatches of the 20 timed steps / 20, three lanes, chained (rocprofv3 serialises dispatches under --pmc)"))
 for key in ("diffuse", "coherent", "v10_diffuse", "xl", "xl_diffuse", "q0_diffuse", "q0_xl"):
     der[key] = derive(pm[key], traces.get(key))
