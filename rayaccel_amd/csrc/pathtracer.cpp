@@ -82,6 +82,17 @@ struct Renderer {
         const uint32_t sample = r->sampleFirst + job / tiles, tile = job % tiles;
         const uint32_t tx = (tile % r->tilesX) * 128, ty = (tile / r->tilesX) * 128;
         LightPath* lp = r->payload.data() + size_t(out->index) * r->info.rayStreamSize;
+#ifdef RACC_PT_SHADE8
+        static const bool scalarOnly = [] { const char* e = std::getenv("RACC_PT_SCALAR"); return e && std::atoi(e) != 0; }();
+        if (!scalarOnly) {
+            for (uint32_t y = 0; y < 128; ++y)
+                for (uint32_t x = 0; x < 128; x += 8) {      // eight pixels of a row at a time (lane k = primaryRay of pixel x + k, bit for bit)
+                    ptshade::simd::primaryRay8(r->scene->cam, tx + x, ty + y, (ty + y) * r->width + tx + x, sample, reinterpret_cast<ptshade::RayRec*>(&out->rays[out->count]), &lp[out->count]);
+                    for (uint32_t k = 0; k < 8; ++k) r->sampleOf(out->index, out->count + k) = sample;
+                    out->count += 8;
+                }
+        } else
+#endif
         for (uint32_t y = 0; y < 128; ++y)
             for (uint32_t x = 0; x < 128; ++x) {
                 const uint32_t pixel = (ty + y) * r->width + tx + x;
@@ -100,8 +111,41 @@ struct Renderer {
         Renderer* r = static_cast<Renderer*>(data);
         const LightPath* lin = r->payload.data() + size_t(in->index) * r->info.rayStreamSize;
         LightPath* lout = r->payload.data() + size_t(out->index) * r->info.rayStreamSize;
-        for (unsigned i = start; i < end; ++i) {
+#ifdef RACC_PT_SHADE8
+        // surface hits are collected eight at a time and shaded by ptshade::simd::shadeSurface8 (lane k = shadeSurface of hit k, bit for bit);
+        // survivors go into the output stream in the order of their rays, as the scalar loop below would put them
+        static const bool scalarOnly = [] { const char* e = std::getenv("RACC_PT_SCALAR"); return e && std::atoi(e) != 0; }();
+        unsigned pending[8], nPending = 0;
+        auto flush8 = [&] {
+            const ptshade::RayRec* rays[8]; const ptshade::HitRec* hits[8]; const LightPath* paths[8]; const ptshade::ShadeTri* tris[8]; uint32_t samples[8];
+            for (unsigned k = 0; k < 8; ++k) {
+                const unsigned i = pending[k];
+                rays[k] = reinterpret_cast<const ptshade::RayRec*>(&in->rays[i]); hits[k] = reinterpret_cast<const ptshade::HitRec*>(&in->results[i]);
+                paths[k] = &lin[i]; samples[k] = r->sampleOf(in->index, i); tris[k] = &r->tris[hits[k]->triangle];
+            }
+            ptshade::RayRec nr[8]; LightPath np[8];
+            unsigned alive = ptshade::simd::shadeSurface8(r->scene->mat, rays, hits, paths, samples, tris, nr, np);
+            for (unsigned k = 0; alive; ++k, alive >>= 1)
+                if (alive & 1u) {
+                    reinterpret_cast<ptshade::RayRec&>(out->rays[out->count]) = nr[k];
+                    lout[out->count] = np[k];
+                    r->sampleOf(out->index, out->count) = samples[k];
+                    ++out->count;
+                }
+            nPending = 0;
+        };
+#endif
+        auto shadeOne = [&](unsigned i) {
             const ptshade::RayRec& ray = reinterpret_cast<const ptshade::RayRec&>(in->rays[i]);
+            const ptshade::HitRec& hit = reinterpret_cast<const ptshade::HitRec&>(in->results[i]);
+            const uint32_t sample = r->sampleOf(in->index, i);
+            const ptshade::ShadeTri& st = r->tris[hit.triangle];
+            if (!ptshade::shadeSurface(r->scene->mat, ray, hit, lin[i], sample, st.n0, st.n1, st.n2, ptshade::Vec{st.ng[0], st.ng[1], st.ng[2]}, st.material,
+                                       reinterpret_cast<ptshade::RayRec&>(out->rays[out->count]), lout[out->count])) return;
+            r->sampleOf(out->index, out->count) = sample;
+            ++out->count;
+        };
+        for (unsigned i = start; i < end; ++i) {
             const ptshade::HitRec& hit = reinterpret_cast<const ptshade::HitRec&>(in->results[i]);
             const LightPath& lp = lin[i];
             if (hit.triangle == racc::invalidTriangle) {                    // PathTracingRenderer.cpp:505-563
@@ -112,18 +156,23 @@ struct Renderer {
                     if (valid[ch]) r->frame[size_t(pixel) * 3 + ch].fetch_add(int64_t(add[ch]), std::memory_order_relaxed);
                 continue;
             }
-            const uint32_t sample = r->sampleOf(in->index, i);
             if ((lp.pixelDepth >> 24) >= r->maxDepth || hit.triangle >= r->view.triangleCount) continue;        // = shadeHit's guard (PathTracingRenderer.cpp:113-114)
-            if (i + 8 < end) {                // the record of a hit a few rays ahead is on its way while this one is shaded
-                const uint32_t ahead = reinterpret_cast<const ptshade::HitRec&>(in->results[i + 8]).triangle;
+            if (i + 16 < end) {               // the record of a hit some rays ahead is on its way while these are shaded
+                const uint32_t ahead = reinterpret_cast<const ptshade::HitRec&>(in->results[i + 16]).triangle;
                 if (ahead < r->view.triangleCount) __builtin_prefetch(&r->tris[ahead]);
             }
-            const ptshade::ShadeTri& st = r->tris[hit.triangle];
-            if (!ptshade::shadeSurface(r->scene->mat, ray, hit, lp, sample, st.n0, st.n1, st.n2, ptshade::Vec{st.ng[0], st.ng[1], st.ng[2]}, st.material,
-                                       reinterpret_cast<ptshade::RayRec&>(out->rays[out->count]), lout[out->count])) continue;
-            r->sampleOf(out->index, out->count) = sample;
-            ++out->count;
+#ifdef RACC_PT_SHADE8
+            if (!scalarOnly) {
+                pending[nPending++] = i;
+                if (nPending == 8) flush8();
+                continue;
+            }
+#endif
+            shadeOne(i);
         }
+#ifdef RACC_PT_SHADE8
+        for (unsigned k = 0; k < nPending; ++k) shadeOne(pending[k]);      // fewer than eight left in this slice: the scalar form (same results, same order)
+#endif
     }
 };
 
@@ -145,6 +194,64 @@ extern "C" void racc_pt_test_sample_material(const float* ke, const float* rnd, 
                                            rnd[3 * i], rnd[3 * i + 1], rnd[3 * i + 2], w, colour + 3 * i) ? 1 : 0;
         wi[3 * i] = w.x; wi[3 * i + 1] = w.y; wi[3 * i + 2] = w.z;
     }
+}
+// Test hook: n random surface interactions (seeded) through ptshade::shadeSurface and, eight at a time, through ptshade::simd::shadeSurface8;
+// returns the number of interactions whose outcome (alive flag, next ray, next payload) differs in any bit, or -1 if this build has no 8-wide form.
+extern "C" long long racc_pt_test_shade8(uint32_t n, uint32_t seed, uint32_t* alive_count) {
+#ifdef RACC_PT_SHADE8
+    ptshade::Materials mat{};
+    const float kds[4][3] = {{0.8f, 0.7f, 0.6f}, {0.1f, 0.9f, 0.2f}, {0.0f, 0.0f, 0.0f}, {0.5f, 0.5f, 0.5f}};
+    const float etas[4] = {1.5f, 1.2f, 2.4f, 0.7f};      // (0.7: total internal reflection for grazing directions)
+    for (int m = 0; m < 4; ++m) { for (int c = 0; c < 3; ++c) mat.kd[m][c] = kds[m][c]; mat.eta[m] = etas[m]; }
+    uint32_t state = seed * 2654435761u + 12345u;
+    auto rnd = [&] { state = ptshade::pcg(state + 0x9E3779B9u); return float(state >> 8) * (1.0f / 16777216.0f); };
+    auto unit = [&](float out[3]) { float x, y, z, l; do { x = rnd() * 2 - 1; y = rnd() * 2 - 1; z = rnd() * 2 - 1; l = x * x + y * y + z * z; } while (l < 1e-3f); l = 1.0f / sqrtf(l); out[0] = x * l; out[1] = y * l; out[2] = z * l; };
+    long long bad = 0; uint32_t aliveTotal = 0;
+    for (uint32_t base = 0; base + 8 <= n; base += 8) {
+        ptshade::RayRec ray[8]; ptshade::HitRec hit[8]; LightPath path[8]; uint32_t sample[8]; ptshade::ShadeTri tri[8];
+        const ptshade::RayRec* rp[8]; const ptshade::HitRec* hp[8]; const LightPath* pp[8]; const ptshade::ShadeTri* tp[8];
+        for (int k = 0; k < 8; ++k) {
+            for (int c = 0; c < 3; ++c) ray[k].origin[c] = rnd() * 200 - 100;
+            unit(ray[k].dir); ray[k].minT = 1e-3f; ray[k].maxT = 1e6f;
+            hit[k].triangle = 0; hit[k].t = rnd() * 300; hit[k].u = rnd(); hit[k].v = rnd() * (1 - hit[k].u);
+            for (int c = 0; c < 3; ++c) path[k].weight[c] = rnd() < 0.1f ? rnd() * 0.02f : rnd();
+            path[k].pixelDepth = (uint32_t(rnd() * 2073600) & 0xFFFFFFu) | (uint32_t(rnd() * 6) << 24);
+            sample[k] = uint32_t(rnd() * 64);
+            unit(tri[k].n0); unit(tri[k].n1); unit(tri[k].n2); unit(tri[k].ng);
+            if (rnd() < 0.05f) { tri[k].n0[0] = tri[k].n1[0] = tri[k].n2[0] = 0.0f; }      // (normals with a small x: the other tangent frame)
+            if (rnd() < 0.01f) hit[k].t = INFINITY;                                         // a non-finite origin: the path dies
+            tri[k].material = uint32_t(rnd() * 4) & 3u; tri[k].pad[0] = tri[k].pad[1] = tri[k].pad[2] = 0;
+            rp[k] = &ray[k]; hp[k] = &hit[k]; pp[k] = &path[k]; tp[k] = &tri[k];
+        }
+        ptshade::RayRec nr8[8]; LightPath np8[8];
+        const unsigned alive8 = ptshade::simd::shadeSurface8(mat, rp, hp, pp, sample, tp, nr8, np8);
+        for (int k = 0; k < 8; ++k) {
+            ptshade::RayRec nr; LightPath np;
+            const bool alive = ptshade::shadeSurface(mat, ray[k], hit[k], path[k], sample[k], tri[k].n0, tri[k].n1, tri[k].n2, ptshade::Vec{tri[k].ng[0], tri[k].ng[1], tri[k].ng[2]}, tri[k].material, nr, np);
+            const bool a8 = ((alive8 >> k) & 1u) != 0;
+            if (alive != a8 || (alive && (std::memcmp(&nr, &nr8[k], sizeof(nr)) != 0 || std::memcmp(&np, &np8[k], sizeof(np)) != 0))) ++bad;
+            aliveTotal += alive ? 1u : 0u;
+        }
+    }
+    // ... and primary rays: 64 x 8 pixels of four samples, the eight-wide form against primaryRay
+    ptshade::Camera cam{{1.5f, 20.0f, -60.0f}, {0.0011f, 0.0f, 0.0002f}, {0.0f, -0.0011f, 0.0001f}, {-0.9f, 0.55f, 0.8f}};
+    for (uint32_t smp = 0; smp < 4; ++smp)
+        for (uint32_t y = 0; y < 64; ++y) {
+            ptshade::RayRec r8[8]; LightPath p8[8];
+            const uint32_t x = (y * 8u) % 1912u, pixel = y * 1920u + x;
+            ptshade::simd::primaryRay8(cam, x, y + 7u, pixel, smp + seed, r8, p8);
+            for (uint32_t k = 0; k < 8; ++k) {
+                ptshade::RayRec r1; LightPath p1;
+                ptshade::primaryRay(cam, x + k, y + 7u, pixel + k, smp + seed, r1, p1);
+                if (std::memcmp(&r1, &r8[k], sizeof(r1)) != 0 || std::memcmp(&p1, &p8[k], sizeof(p1)) != 0) ++bad;
+            }
+        }
+    if (alive_count) *alive_count = aliveTotal;
+    return bad;
+#else
+    (void)n; (void)seed; if (alive_count) *alive_count = 0;
+    return -1;
+#endif
 }
 extern "C" void racc_pt_test_uniform(uint32_t pixel, uint32_t sample, uint32_t depth, uint32_t stream, uint32_t n, float* out) {
     for (uint32_t i = 0; i < n; ++i) out[i] = ptshade::uniformKeyed(ptshade::pathKey(pixel + i, sample), depth, stream);
