@@ -94,7 +94,12 @@ typedef struct racc_hip_options {
                                   racc_hip_synchronize establish completion — the chain's kernels have ended and every published
                                   batch's rays were handed out — and trace whatever the chain did not reach (it had ended before the
                                   batch was linked) with a catch-up kernel; hence results are defined, as before, when the wait
-                                  returns.  3 => round 4's form: every chained launch brings its own kernel + miss-shading kernel */
+                                  returns.  A caller who waits for every batch gains nothing from a chain and would pay for its start and
+                                  end (0.46 against 0.35 ms per 1M-ray batch): with the default threshold (chain_min_rays = 0), after
+                                  two waits in a row that found a chain of one batch, a batch issued while nothing else of the
+                                  context is in flight is launched stand-alone; the first batch issued while another is in flight
+                                  starts a chain again (RACC_CHAIN_SOLO=0 switches that off).  3 => round 4's form: every chained
+                                  launch brings its own kernel + miss-shading kernel */
     uint32_t chain_min_rays;   /* only batches of at least this many rays are chained; smaller ones are launched stand-alone on their
                                   lane (they overlap like any two lanes' launches).  A chained launch costs the host more stream
                                   operations, and a batch that is worked off before its successor is linked breaks the chain: 27,648-ray

@@ -173,6 +173,8 @@ struct racc_hip_ctx {
     struct ChainHostDesc { const void* rays; void* results; uint32_t count; const racc_hip_scene* scene; const racc_hip_env* env; const void* variant; uint32_t chunk; };
     ChainHostDesc chainHost[kChainRing];
     std::vector<uint32_t> chainOutstanding;      // ring slots published since the last finishChain
+    uint32_t chainSoloWaits = 0;         // consecutive waits that found a chain of exactly ONE batch: a caller who issues a batch and waits for it (launchTraverse: such a caller's batches stand alone)
+    bool chainSoloPolicy = true;         // ... only with the default threshold: a context given chain_min_rays / RACC_CHAIN_MIN chains every batch of that size, as asked (RACC_CHAIN_SOLO=0 switches the policy off too)
     Lane chainLane;                      // stream + spill area of the catch-up kernels (finishChainLocked)
     bool chainEnabled = true;            // RACC_CHAIN=0 switches it off
     uint32_t chainMinRays = 3u << 18;    // (786,432) smaller batches are launched stand-alone (launchTraverse); RACC_CHAIN_MIN overrides
@@ -302,8 +304,9 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
         ctx->chainLazy = ctx->opts.chain_launches != 3u;
         if (const char* c = std::getenv("RACC_CHAIN_LAZY")) ctx->chainLazy = std::atoi(c) != 0;
         if (const char* c = std::getenv("RACC_RAY_SCOPE")) ctx->raysBypassL1 = std::atoi(c) != 0;
-        if (ctx->opts.chain_min_rays) ctx->chainMinRays = ctx->opts.chain_min_rays;
-        if (const char* c = std::getenv("RACC_CHAIN_MIN")) ctx->chainMinRays = uint32_t(std::atoll(c));
+        if (ctx->opts.chain_min_rays) { ctx->chainMinRays = ctx->opts.chain_min_rays; ctx->chainSoloPolicy = false; }
+        if (const char* c = std::getenv("RACC_CHAIN_MIN")) { ctx->chainMinRays = uint32_t(std::atoll(c)); ctx->chainSoloPolicy = false; }
+        if (const char* c = std::getenv("RACC_CHAIN_SOLO")) ctx->chainSoloPolicy = std::atoi(c) != 0;
         hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&ctx->chainDev), sizeof(ChainDesc) * racc_hip_ctx::kChainRing);
         if (e1 == hipSuccess) e1 = hipMemset(ctx->chainDev, 0, sizeof(ChainDesc) * racc_hip_ctx::kChainRing);
         if (e1 == hipSuccess) {      // highest priority: a publish kernel must not wait behind the persistent waves it is meant to feed

@@ -182,3 +182,43 @@ def test_default_threshold_interleaves_chained_and_stand_alone_batches(full, ful
         for d in d_sets + big_outs + small_outs:
             d.free()
         scene.destroy(); env.destroy()
+
+
+def test_a_caller_who_waits_for_every_batch_gets_stand_alone_launches(full, full_q1):
+    """Round 5: starting and finishing a chain costs a third of a lone 1M-ray batch's time (0.46 against 0.35 ms).  On a default-options
+    context, after two waits in a row that found a chain of ONE batch, a batch issued while nothing else is in flight is launched stand-alone
+    (the lazy chain's kernel has a miss queue in LDS: racc_hip_get_launch_info tells the two apart); the first batch issued while another is
+    still in flight starts a chain again.  Every record of every batch against the oracle, across the switches."""
+    sc, host = full["sc"], full_q1["host"]
+    n = 1 << 20
+    with ra.Context(device=0, lanes=3) as ctx:
+        scene = ctx.upload_scene(host.nodes, host.pairs, host.remap)
+        env = ctx.create_environment(sc["env"])
+        hits = ctx.intersect(scene, env, full["primary"])
+        sets = synth.diffuse_bounce_batches(sc, full["primary"], hits, n, range(2))
+        refs = [orc.traverse(full_q1["blobs"], r, env=sc["env"], threads=8) for r in sets]
+        d_sets = []
+        for r in sets:
+            d = ctx.alloc(r.nbytes); d.upload(r); d_sets.append(d)
+        outs = [ctx.alloc(n * 16) for _ in range(6)]
+        lds = []
+        for k in range(5):                       # issue, wait, issue, wait ...
+            ctx.intersect_device(scene, env, d_sets[k % 2].ptr, outs[0].ptr, n, lane=0)
+            ctx.wait(0)
+            lds.append(ctx.launch_info(0)["lds_bytes_per_block"])
+            assert_bit_exact(outs[0].download(ra.RESULT_DTYPE, n), refs[k % 2], "lone batch %d" % k)
+        assert lds[0] == lds[1] and lds[2] == lds[3] == lds[4] and lds[2] < lds[0], lds          # two chained (with the miss queue), then stand-alone
+        for rnd in range(2):                     # back to back: the second batch finds the first in flight and starts a chain; the rest follow it
+            for k in range(6):
+                ctx.intersect_device(scene, env, d_sets[k % 2].ptr, outs[k].ptr, n, lane=k % 3)
+            assert ctx.launch_info(1)["lds_bytes_per_block"] == lds[0]
+            ctx.wait(ra.LANE_AUTO)
+            for k in range(6):
+                assert_bit_exact(outs[k].download(ra.RESULT_DTYPE, n), refs[k % 2], "back to back, round %d, batch %d" % (rnd, k))
+        for k in range(4):                       # ... and alone again
+            ctx.intersect_device(scene, env, d_sets[k % 2].ptr, outs[0].ptr, n, lane=ra.LANE_AUTO)
+            ctx.wait(ra.LANE_AUTO)
+            assert_bit_exact(outs[0].download(ra.RESULT_DTYPE, n), refs[k % 2], "lone batch again %d" % k)
+        for d in d_sets + outs:
+            d.free()
+        scene.destroy(); env.destroy()
