@@ -341,7 +341,7 @@ int racc_host_scene_build(const float* vertices, uint32_t vertex_count,
  * enlarge the boxes above them least (Bittner et al. 2013; parallel over fixed subtrees, so still deterministic for any thread
  * count).  The blobs stay in the reference's format (Scene.cpp:73-87) and the reference's traversal order applies unchanged: the
  * oracle and the reference's own OpenCL kernel consume them as they are; only the number of node visits and pair tests per ray
- * drops (battlefield-synth, first-bounce rays: 51.1 -> 45.7 visits, 3.44 -> 2.70 pair tests at quality 1).  Hit records of a quality
+ * drops (battlefield-synth, first-bounce rays: 51.1 -> 45.2 visits, 3.44 -> 2.70 pair tests at quality 1).  Hit records of a quality
  * tree equal those of the quality-0 tree up to how a triangle happens to be paired (t/u/v within rounding, primId up to
  * exact-distance ties).  threads 0 = RACC_BUILD_THREADS, else the CPUs this process may use. */
 typedef struct racc_host_build_options {
