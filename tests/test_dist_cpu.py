@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the N>1 path (ray sharding + Result all-gather) on CPU.  The GPU engine
+"""world_size-2 and -8 gloo tests of the N>1 path (ray sharding + Result all-gather) on CPU.  The GPU engine
 cannot run here, so each rank uses the ORACLE as its intersector — the thing under test is the sharding
 / gather plumbing of rayaccel_amd/shard.py, which is device-agnostic."""
 import os
@@ -48,17 +48,19 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_shard_and_allgather():
+@pytest.mark.parametrize("world", [2, 8])      # 8 = the rank count of BASELINE configs[3] (one rank per GPU of the node): ragged shards of 512 / 513 rays
+def test_ranks_shard_and_allgather(world):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
-    res = sorted(q.get(timeout=180) for _ in procs)
+    res = sorted(q.get(timeout=300) for _ in procs)
     [p.join(60) for p in procs]
-    assert [r[1] for r in res] == [True, True]
-    assert sum(r[2] for r in res) == 4099
+    assert [r[0] for r in res] == list(range(world))
+    assert [r[1] for r in res] == [True] * world
+    assert sum(r[2] for r in res) == 4099 and max(r[2] for r in res) - min(r[2] for r in res) <= 1
 
 
 def test_bench_plain_command_re_executes_under_the_launcher(tmp_path):
