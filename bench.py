@@ -66,6 +66,22 @@ def committed_profile():
     return d
 
 
+def steady_state_profile():
+    """The limiter counters of 8M-ray launches (tools/r5_steady_pmc.sh -> profiles/<round>/steady_state_pmc.json): what the kernel does with its
+    waves full, beside the isolated 1M-ray launch `limiter` describes.  None when missing; `stale` as for committed_profile()."""
+    try:
+        with open(os.path.join(ROOT, PROFILE_DIR, "steady_state_pmc.json")) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    keep = ("kernel_ms", "mrays_per_s", "wave_time_split", "valu_busy_frac", "valu_lane_util", "td_busy_frac", "ta_busy_frac", "salu_share",
+            "valu_insts_per_ray", "vmem_rd_insts_per_ray", "l2_hit_rate")
+    out = {"what": "the same counters for 8M-ray launches of the same kernel and tree (no ramp-up / drain share): %s/steady_state_pmc.json" % PROFILE_DIR}
+    out.update({k: d.get(k) for k in keep})
+    out["stale"] = d.get("kernel_source_sha256") != kernel_source_sha256()
+    return out
+
+
 def gather_ceiling():
     """Best rate at which a pure gather of random 64 B records runs on this part, bytes per clock per CU: measured by
     tools/microbench/gather64.hip (mode 2: quad-cooperative LDS-DMA), output committed under profiles/<round>/ by
@@ -687,6 +703,7 @@ def main():
                 "limiter": None if not pw else {k: pw.get(k) for k in (
                     "bound", "wave_time_split", "td_busy_frac", "ta_busy_frac", "valu_busy_frac", "valu_lane_util", "salu_share",
                     "l2_hit_rate", "vmem_rd_insts_per_ray", "valu_insts_per_ray", "kernel_ms_isolated", "write_x_compulsory")},
+                "limiter_steady_state": steady_state_profile() if (on_profiled_workload and args.workload == "diffuse" and args.quality == 1) else None,
                 "profile_source": (prof or {}).get("source"),
                 "profile_stale": bool(prof["stale"]) if prof else None})
             # the other configs beside configs[2] (the headline): same definitions

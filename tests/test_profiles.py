@@ -22,3 +22,16 @@ def test_committed_profile_matches_the_kernel_sources():
     assert os.path.exists(os.path.join(ROOT, bench.PROFILE_DIR, "gather64.txt"))
     stats = open(os.path.join(ROOT, bench.PROFILE_DIR, "kernel_stats.csv")).read()
     assert bench.KERNEL_NAME in stats
+
+
+def test_steady_state_counters_match_the_kernel_sources():
+    """profiles/<round>/steady_state_pmc.json (tools/r5_steady_pmc.sh: the limiter counters of 8M-ray launches) is reported by bench.py as
+    `roofline.limiter_steady_state`: same staleness rule, and the fractions are fractions."""
+    import bench
+    st = bench.steady_state_profile()
+    assert st is not None and not st["stale"], "kernel sources changed after steady_state_pmc.json was taken: re-run tools/r5_steady_pmc.sh"
+    for key in ("valu_busy_frac", "valu_lane_util", "td_busy_frac", "ta_busy_frac", "l2_hit_rate"):
+        assert 0 < st[key] <= 1, key
+    w = st["wave_time_split"]
+    assert 0.95 < w["waiting"] + w["issue_stalled"] + w["executing"] < 1.02      # disjoint states of a resident wave
+    assert st["vmem_rd_insts_per_ray"] > 2 and st["valu_insts_per_ray"] > 40

@@ -17,7 +17,10 @@ rays, CUS, SIMDS, XCDS = 8 << 20, 256, 1024, 8
 cycles = c["GRBM_GUI_ACTIVE"] / XCDS
 wc = c["SQ_WAVE_CYCLES"]
 insts = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
-d = dict(what="traverseKernelV8 (default), 8M first-bounce diffuse rays per launch on the quality tree, the kernel alone on the GPU (one lane, no chaining): "
+import sys
+sys.path.insert(0, ".")
+import bench
+d = dict(kernel_source_sha256=bench.kernel_source_sha256(), what="traverseKernelV8 (default), 8M first-bounce diffuse rays per launch on the quality tree, the kernel alone on the GPU (one lane, no chaining): "
               "means over the 20 timed launches, one rocprofv3 --pmc run per counter set; formulas as in derived.json",
          kernel_ms=round(cycles / 2.4e6, 4), mrays_per_s=round(rays / (cycles / 2.4e9) / 1e6, 1),
          wave_time_split=dict(waiting=round(c["SQ_WAIT_ANY"] / wc, 4), issue_stalled=round(c["SQ_WAIT_INST_ANY"] / wc, 4), executing=round(c["SQ_ACTIVE_INST_ANY"] / wc, 4)),
