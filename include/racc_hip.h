@@ -330,12 +330,15 @@ int racc_hip_comm_destroy(racc_hip_comm* comm);
  * leaf pair merge (Scene.cpp:237-261) → 64 B node flatten (Scene.cpp:275-332) → pair padding
  * (Scene.cpp:334-338).  vertices: xyzw floats, 16-byte aligned (Scene.cpp:187); index_count % 3 == 0
  * (Scene.cpp:186).  Deterministic (the reference's node numbering is thread-timing dependent).
- * = racc_host_scene_build_ex with options NULL: the reference's builder, unless the environment variable RACC_BUILD_QUALITY
- * (0, 1, 2) asks for a quality tree — the switch for callers that pass no options (racc::createScene, the path-tracing consumers). */
+ * = racc_host_scene_build_ex with options NULL: the library default, RACC_HOST_BUILD_DEFAULT_QUALITY — the quality-1 tree (below; the
+ * same reference-format blobs with fewer node visits per ray; it is the tree bench.py's headline figure is measured on, so a drop-in caller
+ * of racc::createScene gets what is benchmarked) — unless the environment variable RACC_BUILD_QUALITY (0, 1, 2) says otherwise; 0 there, or
+ * racc_host_build_options.quality = 0, gives the reference's own builder (Bvh2.cpp:257-535), byte-identical to the oracle's restatement. */
+#define RACC_HOST_BUILD_DEFAULT_QUALITY 1u
 int racc_host_scene_build(const float* vertices, uint32_t vertex_count,
                           const uint32_t* indices, uint32_t index_count,
                           racc_host_scene** out);
-/* The same with options.  quality 0 = the reference's builder, byte-identical to racc_host_scene_build.  quality 1 / 2 (no
+/* The same with options.  quality 0 = the reference's builder.  quality 1 (= racc_host_scene_build) / 2 (no
  * counterpart in the reference): the finished tree is post-processed — every leaf cut down to ONE triangle pair (the reference
  * leaves up to six in a leaf, and every pair of a visited leaf is tested, Kernels.h:200-205), then subtrees re-inserted where they
  * enlarge the boxes above them least (Bittner et al. 2013; parallel over fixed subtrees, so still deterministic for any thread

@@ -184,26 +184,37 @@ def device_count():
     return n.value if rc == 0 else 0
 
 
+LIBRARY_DEFAULT_QUALITY = 1      # RACC_HOST_BUILD_DEFAULT_QUALITY (include/racc_hip.h); tests/test_abi.py holds the two together
+
+
 class HostBuildOptions(C.Structure):
     """racc_host_build_options (include/racc_hip.h)."""
     _fields_ = [("struct_size", _u32), ("quality", _u32), ("threads", _u32), ("reserved", _u32 * 5)]
 
 
 class HostScene:
-    """Host-side build product ≙ the GPU branch of racc::createScene (Scene.cpp:216-339).  quality 0 = the reference's builder
-    (byte-identical to the oracle's restatement); 1 / 2 = the same format with fewer node visits per ray (racc_host_scene_build_ex)."""
+    """Host-side build product ≙ the GPU branch of racc::createScene (Scene.cpp:216-339).  quality 0 (this harness's default: the tree the
+    oracle's builder restates byte for byte) = the reference's builder; 1 / 2 = the same format with fewer node visits per ray; an integer
+    is always passed as explicit options (racc_host_scene_build_ex), so no environment variable can change what it means.  quality=None =
+    the LIBRARY's default — what racc::createScene and every other caller of the plain racc_host_scene_build gets: quality 1 since round 6
+    (RACC_HOST_BUILD_DEFAULT_QUALITY), RACC_BUILD_QUALITY overrides it; `self.quality` then says which tree was built."""
 
     def __init__(self, vertices, indices, quality=0, threads=0):
         lib = load_library()
         v = _as_verts4(vertices)
         idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
         h = C.c_void_p()
-        self.quality = int(quality)
-        if quality or threads:
+        if quality is None and not threads:
+            env = os.environ.get("RACC_BUILD_QUALITY")
+            self.quality = max(0, int(env)) if env not in (None, "") else LIBRARY_DEFAULT_QUALITY
+            _check(lib.racc_host_scene_build(_ptr(v), len(v), _ptr(idx), idx.size, C.byref(h)))
+        else:
+            if quality is None:
+                env = os.environ.get("RACC_BUILD_QUALITY")
+                quality = max(0, int(env)) if env not in (None, "") else LIBRARY_DEFAULT_QUALITY
+            self.quality = int(quality)
             opt = HostBuildOptions(struct_size=C.sizeof(HostBuildOptions), quality=int(quality), threads=int(threads))
             _check(lib.racc_host_scene_build_ex(_ptr(v), len(v), _ptr(idx), idx.size, C.byref(opt), C.byref(h)))
-        else:
-            _check(lib.racc_host_scene_build(_ptr(v), len(v), _ptr(idx), idx.size, C.byref(h)))
         try:
             pn, pp, pr = C.c_void_p(), C.c_void_p(), C.c_void_p()
             nn, npad, npair, nr = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
@@ -343,8 +354,8 @@ class Context:
         return Scene(self, h)
 
     def create_scene(self, vertices, indices):
-        """≙ racc::createScene (RayAccelerator.h:107): host build, then upload."""
-        hs = HostScene(vertices, indices)
+        """≙ racc::createScene (RayAccelerator.h:107): host build with the library's default options, then upload."""
+        hs = HostScene(vertices, indices, quality=None)
         return self.upload_scene(hs.nodes, hs.pairs, hs.remap)
 
     def create_environment(self, colors):

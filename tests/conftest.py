@@ -36,6 +36,20 @@ def small_host(small_scene):
 
 
 @pytest.fixture(scope="session")
+def small_default_host(small_scene):
+    """The small scene as racc::createScene builds it (library default options: the quality-1 tree, RACC_HOST_BUILD_DEFAULT_QUALITY)."""
+    import rayaccel_amd
+    return rayaccel_amd.HostScene(small_scene["vertices"], small_scene["indices"], quality=None)
+
+
+@pytest.fixture(scope="session")
+def full_default_blobs(full):
+    """battlefield-synth as racc::createScene builds it (library default options), for tests that re-trace what racc::render traced."""
+    import rayaccel_amd as ra
+    return ra.HostScene(full["sc"]["vertices"], full["sc"]["indices"], quality=None).blobs()
+
+
+@pytest.fixture(scope="session")
 def gpu_ctx():
     import rayaccel_amd
     # chain_min_rays=1: the suite's shared context chains EVERY device-resident batch, as rounds 2-3 did, so that the chained path keeps
@@ -52,7 +66,7 @@ def full(gpu_ctx):
     import rayaccel_amd as ra
     from rayaccel_amd import synth
     sc = synth.battlefield_synth()
-    host = ra.HostScene(sc["vertices"], sc["indices"])
+    host = ra.HostScene(sc["vertices"], sc["indices"])          # quality 0: the reference builder's tree (leaves of up to six pairs)
     scene = gpu_ctx.upload_scene(host.nodes, host.pairs, host.remap)
     env = gpu_ctx.create_environment(sc["env"])
     prim, _ = synth.primary_rays(sc["camera"], 1024, 1024)

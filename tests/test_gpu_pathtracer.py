@@ -81,7 +81,7 @@ def test_config4_1080p_device_and_host_consumer_render_the_same_frame(tmp_path, 
     assert np.array_equal(g, c) and g[:1024].any() and not g[1024:].any()
 
 
-def test_config4_1080p_64spp_equals_sixteen_shards_and_a_bounce_is_retraced(tmp_path, full):
+def test_config4_1080p_64spp_equals_sixteen_shards_and_a_bounce_is_retraced(tmp_path, full, full_default_blobs):
     """BASELINE configs[4] as written: 1920x1080 x 64 spp, device-resident consumer.  The fixed-point frame and the ray count
     equal the sum of 16 shards of 4 spp (what N ranks render, tools/pathtrace.py), and one bounce of the 64-spp render — the
     rays the consumer's shading kernel generated and handed to the engine in round 5, the hit records it got back — is
@@ -97,7 +97,7 @@ def test_config4_1080p_64spp_equals_sixteen_shards_and_a_bounce_is_retraced(tmp_
     n = int(count.value)
     assert n > 100000 and sw["primary_rays"] == 64 * 15 * 8 * 128 * 128 and sw["rays_traced"] > 2 * sw["primary_rays"]
     assert float(rays["minT"][:n].max()) > 0.0          # a secondary bounce (primaries start at minT = 0, PathTracingRenderer.cpp:410-422)
-    ref = orc.traverse(full["blobs"], rays[:n], env=full["sc"]["env"], threads=8)
+    ref = orc.traverse(full_default_blobs, rays[:n], env=full["sc"]["env"], threads=8)      # (the consumer builds its scene with the library default: the quality-1 tree)
     assert_bit_exact(hits[:n], ref, "device consumer, 64 spp, round 5 (%d rays)" % n)
     total, traced = np.zeros_like(whole), 0
     for k in range(16):

@@ -38,8 +38,9 @@ def _run(tmp_path, sc, w, h, depth, frames=1, env=None):
 @pytest.mark.parametrize("cfg", [dict(), dict(RACC_CPU_THREADS="3", RACC_BATCH="20000"),
                                  # starved scheduler: tiny streams, few rays in flight, one lane, small shade batches
                                  dict(RACC_CPU_THREADS="5", RACC_BATCH="1024", RACC_IN_FLIGHT="40000", RACC_GPU_THREADS="1", RACC_SHADE_BATCH="300"),
-                                 dict(RACC_CPU_THREADS="1", RACC_BATCH="16384", RACC_IN_FLIGHT="16384", RACC_GPU_THREADS="4")])
-def test_render_matches_oracle(tmp_path, small_scene, small_host, cfg):
+                                 dict(RACC_CPU_THREADS="1", RACC_BATCH="16384", RACC_IN_FLIGHT="16384", RACC_GPU_THREADS="4"),
+                                 dict(RACC_BUILD_QUALITY="0")])      # the reference builder's tree (racc::createScene builds quality 1 by default)
+def test_render_matches_oracle(tmp_path, small_scene, small_host, small_default_host, cfg):
     assert ra.RAY_DTYPE.itemsize == 32
     info, recs = _run(str(tmp_path), small_scene, 512, 384, 3, frames=2, env=cfg)
     prim = recs[recs["depth"] == 0]
@@ -48,7 +49,8 @@ def test_render_matches_oracle(tmp_path, small_scene, small_host, cfg):
     hits_d0 = int((prim["res"]["triangle"] != MISS).sum())
     assert int((recs["depth"] == 1).sum()) == hits_d0                      # one bounce per depth-0 hit, none lost
     assert recs["depth"].max() == 2
-    ref = orc.traverse(small_host.blobs(), np.ascontiguousarray(recs["ray"]), env=small_scene["env"], threads=8)
+    blobs = (small_host if cfg.get("RACC_BUILD_QUALITY") == "0" else small_default_host).blobs()      # what racc::createScene built in that run
+    ref = orc.traverse(blobs, np.ascontiguousarray(recs["ray"]), env=small_scene["env"], threads=8)
     got = np.ascontiguousarray(recs["res"])
     assert np.array_equal(got["triangle"], ref["triangle"])
     hit = ref["triangle"] != MISS
@@ -68,20 +70,20 @@ def _check_against_oracle(recs, blobs, env):
     return ref
 
 
-def test_one_context_over_two_engine_contexts(tmp_path, small_scene, small_host):
+def test_one_context_over_two_engine_contexts(tmp_path, small_scene, small_default_host):
     """Multi-device behind the boundary (racc::gpuContextForDevices), rehearsed on the one GPU of the test box with the entry
     list 0,0: two engine contexts, scene and environment replicated, ray streams sharded over them as whole streams.  Same
     rays, same results, none lost or duplicated."""
     info, recs = _run(str(tmp_path), small_scene, 512, 384, 3, frames=2, env=dict(RACC_DEVICES="0,0", RACC_BATCH="8192"))
     info1, recs1 = _run(str(tmp_path), small_scene, 512, 384, 3, frames=2, env=dict(RACC_BATCH="8192"))
     assert len(recs) == len(recs1)
-    _check_against_oracle(recs, small_host.blobs(), small_scene["env"])
+    _check_against_oracle(recs, small_default_host.blobs(), small_scene["env"])
     key = lambda r: np.lexsort((r["ray"]["dir"][:, 2], r["ray"]["dir"][:, 0], r["depth"], r["pixel"]))
     a, b = recs[key(recs)], recs1[key(recs1)]
     assert a.tobytes() == b.tobytes()              # the same set of (pixel, depth, ray, result) records as with one engine context
 
 
-def test_config0_64k_primary_rays_on_the_full_scene(tmp_path, full):
+def test_config0_64k_primary_rays_on_the_full_scene(tmp_path, full, full_default_blobs):
     """BASELINE configs[0]: battlefield-synth (1.07 M triangles), 256x256 pinhole-coherent primary rays through racc::render
     (spawn tiles of 128x128 as TiledRenderer.cpp:55-67 does; the reference runs this config on its CPU path, which needs Embree —
     here the same plumbing feeds the GPU).  Every ray re-traced by the oracle."""
@@ -89,11 +91,11 @@ def test_config0_64k_primary_rays_on_the_full_scene(tmp_path, full):
     info, recs = _run(str(tmp_path), sc, 256, 256, 1, frames=1)
     assert len(recs) == 65536 and info["raysTraced"] == 65536
     assert np.array_equal(np.sort(recs["pixel"]), np.arange(65536, dtype=np.uint32))
-    ref = _check_against_oracle(recs, full["blobs"], sc["env"])
+    ref = _check_against_oracle(recs, full_default_blobs, sc["env"])
     assert (ref["triangle"] != MISS).mean() > 0.3
 
 
-def test_config4_1080p_ray_streams_retraced_by_the_oracle(tmp_path, full):
+def test_config4_1080p_ray_streams_retraced_by_the_oracle(tmp_path, full, full_default_blobs):
     """BASELINE configs[4]'s ray streams at full size: 1920x1080 primaries (15x8 tiles = 1,966,080 rays) plus their first
     bounce through racc::render on battlefield-synth; every one of the ~3 M traced rays re-traced by the oracle."""
     sc = full["sc"]
@@ -101,7 +103,7 @@ def test_config4_1080p_ray_streams_retraced_by_the_oracle(tmp_path, full):
     prim = recs[recs["depth"] == 0]
     assert len(prim) == 15 * 8 * 128 * 128
     assert int((recs["depth"] == 1).sum()) == int((prim["res"]["triangle"] != MISS).sum()) > 500000
-    _check_against_oracle(recs, full["blobs"], sc["env"])
+    _check_against_oracle(recs, full_default_blobs, sc["env"])
 
 
 def test_create_context_without_gpu_context_fails_loudly(tmp_path):
@@ -119,10 +121,10 @@ def test_create_context_without_gpu_context_fails_loudly(tmp_path):
 def test_null_callbacks_scheduler_rate(tmp_path, small_scene):
     """render_check --null-callbacks: racc::render with callbacks that cost nothing (spawn = one memcpy of a pre-generated tile, shade
     consumes and emits nothing) — the scheduler + host RayStream path alone (what bench.py reports as `scheduler_only_null_callbacks`).
-    Every spawned ray is traced and handed to shade exactly once; with RACC_BUILD_QUALITY=1 racc::createScene builds the quality tree."""
+    Every spawned ray is traced and handed to shade exactly once; with RACC_BUILD_QUALITY=0 racc::createScene builds the reference builder's tree."""
     scene_file = os.path.join(str(tmp_path), "scene.bin")
     synth.write_scene_bin(scene_file, small_scene)
-    for env in (dict(), dict(RACC_BUILD_QUALITY="1"), dict(RACC_CPU_THREADS="2", RACC_GPU_THREADS="1", RACC_BATCH="4096")):
+    for env in (dict(), dict(RACC_BUILD_QUALITY="0"), dict(RACC_CPU_THREADS="2", RACC_GPU_THREADS="1", RACC_BATCH="4096")):
         p = subprocess.run([BIN, scene_file, "--null-callbacks", "1024", "512", "3", "3"], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stdout + p.stderr
         info = json.loads(p.stdout.strip().splitlines()[-1])

@@ -199,15 +199,25 @@ def test_tiny_and_degenerate_inputs():
     check_tree(ra.HostScene(v, idx, quality=1), sc, one_pair_leaves=True)
 
 
-def test_environment_switch_for_callers_without_options(scene, monkeypatch):
-    """RACC_BUILD_QUALITY: what racc::createScene and the path-tracing consumers (callers of the plain racc_host_scene_build) are switched with."""
+def test_callers_without_options_get_the_quality_tree_and_the_environment_can_switch_them(scene, monkeypatch):
+    """racc_host_scene_build (no options: racc::createScene, the path-tracing consumers) builds RACC_HOST_BUILD_DEFAULT_QUALITY = 1 — the tree
+    bench.py's `value` is measured on — unless RACC_BUILD_QUALITY says otherwise; explicit options always win."""
+    monkeypatch.delenv("RACC_BUILD_QUALITY", raising=False)
+    q0 = ra.HostScene(scene["vertices"], scene["indices"], quality=0)
     q1 = ra.HostScene(scene["vertices"], scene["indices"], quality=1)
+    same = lambda a, b: a.nodes.tobytes() == b.nodes.tobytes() and a.pairs.tobytes() == b.pairs.tobytes() and a.remap.tobytes() == b.remap.tobytes()
+    assert not same(q0, q1)
+    default = ra.HostScene(scene["vertices"], scene["indices"], quality=None)
+    assert default.quality == ra.engine.LIBRARY_DEFAULT_QUALITY == 1 and same(default, q1)
+    monkeypatch.setenv("RACC_BUILD_QUALITY", "0")
+    via_env = ra.HostScene(scene["vertices"], scene["indices"], quality=None)
+    assert via_env.quality == 0 and same(via_env, q0)
     monkeypatch.setenv("RACC_BUILD_QUALITY", "1")
-    via_env = ra.HostScene(scene["vertices"], scene["indices"])
-    assert via_env.nodes.tobytes() == q1.nodes.tobytes() and via_env.pairs.tobytes() == q1.pairs.tobytes() and via_env.remap.tobytes() == q1.remap.tobytes()
-    explicit0 = ra.HostScene(scene["vertices"], scene["indices"], quality=0, threads=2)      # explicit options win over the environment
-    monkeypatch.delenv("RACC_BUILD_QUALITY")
-    assert explicit0.nodes.tobytes() == ra.HostScene(scene["vertices"], scene["indices"]).nodes.tobytes()
+    assert same(ra.HostScene(scene["vertices"], scene["indices"], quality=0, threads=2), q0)      # explicit options win over the environment
+    assert same(ra.HostScene(scene["vertices"], scene["indices"]), q0)                            # ... and the harness's integer default is explicit
+    import re, os
+    header = open(os.path.join(os.path.dirname(__file__), "..", "include", "racc_hip.h")).read()
+    assert int(re.search(r"#define RACC_HOST_BUILD_DEFAULT_QUALITY (\d+)u", header).group(1)) == ra.engine.LIBRARY_DEFAULT_QUALITY
 
 
 def test_options_are_validated(scene):
