@@ -146,6 +146,95 @@ def battlefield_synth_xl(grid=XL_GRID, seed=SCENE_SEED):
     return sc
 
 
+# ------------------------------------------------------- two more scene classes (round 6)
+# battlefield-synth is one family: a connected height-field with small things on it.  These two have different statistics — what a tree
+# builder and a traversal kernel tuned on one family must also survive (DESIGN.md §7 holds the three-row table).
+_BOX_CORNERS = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], dtype=np.float64)
+_BOX_FACES = np.array([[0, 3, 2], [0, 2, 1], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4],
+                       [3, 7, 6], [3, 6, 2], [0, 4, 7], [0, 7, 3], [1, 2, 6], [1, 6, 5]], dtype=np.int64)
+
+
+def city_synth(blocks=88, windows=(3, 5), seed=SCENE_SEED ^ 0xC17F, extent=100.0):
+    """Axis-aligned "city": a ground plane of few LARGE triangles (8 x 8 quads over the whole extent), one box-shaped building per cell
+    of a blocks x blocks street grid (heights spread over 1.5 decades), and on every facade a grid of SMALL window-sill quads standing
+    2 cm proud of the wall.  Everything axis-aligned; triangle areas span seven orders of magnitude; nearly every ray that enters a
+    street canyon grazes long coplanar walls.  Defaults: 128 + 7,744 x (12 + 4 x 15 x 2) = 1,022,336 triangles."""
+    cell = 2.0 * extent / blocks
+    g = np.linspace(-extent, extent, 9)
+    gx, gz = np.meshgrid(g, g, indexing="xy")
+    gv = np.stack([gx, np.zeros_like(gx), gz], -1).reshape(-1, 3)
+    j, i = np.meshgrid(np.arange(8), np.arange(8), indexing="xy")
+    a = (i * 9 + j).reshape(-1); b = a + 1; c = a + 10; d = a + 9
+    verts, idx = [gv], [np.concatenate([np.stack([a, c, b], 1), np.stack([a, d, c], 1)], 1).reshape(-1, 3)]
+    base = len(gv)
+    k = np.arange(blocks * blocks)
+    bx, bz = k % blocks, k // blocks
+    cx = -extent + (bx + 0.5) * cell
+    cz = -extent + (bz + 0.5) * cell
+    hx = cell * (0.25 + 0.12 * hash_uniform(k, 61, seed).astype(np.float64))
+    hz = cell * (0.25 + 0.12 * hash_uniform(k, 62, seed).astype(np.float64))
+    hy = 0.5 * 10.0 ** (0.3 + 1.4 * hash_uniform(k, 63, seed).astype(np.float64) ** 2)          # half height: 1 .. 25
+    ctr = np.stack([cx, hy, cz], 1)
+    half = np.stack([hx, hy, hz], 1)
+    bv = (ctr[:, None, :] + _BOX_CORNERS[None] * half[:, None, :]).reshape(-1, 3)
+    verts.append(bv); idx.append((base + 8 * k[:, None, None] + _BOX_FACES[None]).reshape(-1, 3)); base += len(bv)
+    wx, wy = windows
+    if wx and wy:
+        fu, fv = np.meshgrid((np.arange(wx) + 0.5) / wx * 2 - 1, (np.arange(wy) + 0.5) / wy * 2 - 1, indexing="xy")
+        fu, fv = fu.reshape(-1), fv.reshape(-1)                                                 # window centres on a facade, in [-1, 1]^2
+        su, sv = 0.55 / wx, 0.35 / wy
+        quad = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]], dtype=np.float64)
+        for axis, sign in ((0, 1.0), (0, -1.0), (2, 1.0), (2, -1.0)):                           # facades +x, -x, +z, -z
+            other = 2 - axis
+            w = np.zeros((len(k), len(fu), 4, 3))
+            w[..., axis] = (ctr[:, axis] + sign * (half[:, axis] + 0.02))[:, None, None]
+            w[..., other] = ctr[:, other][:, None, None] + half[:, other][:, None, None] * (fu[None, :, None] + su * quad[None, None, :, 0])
+            w[..., 1] = ctr[:, 1][:, None, None] + half[:, 1][:, None, None] * (fv[None, :, None] + sv * quad[None, None, :, 1])
+            wv = w.reshape(-1, 3)
+            q = np.arange(len(k) * len(fu))
+            verts.append(wv); idx.append((base + 4 * q[:, None, None] + np.array([[0, 1, 2], [0, 2, 3]])[None]).reshape(-1, 3)); base += len(wv)
+    v3 = np.concatenate(verts, 0).astype(np.float32)
+    vertices = np.concatenate([v3, np.ones((len(v3), 1), np.float32)], 1)
+    camera = dict(origin=np.array([-0.93 * extent, 0.42 * extent, -0.81 * extent], np.float32), target=np.array([0.1 * extent, 2.0, 0.05 * extent], np.float32),
+                  up=np.array([0.0, 1.0, 0.0], np.float32), fov=55.0)
+    return dict(vertices=np.ascontiguousarray(vertices), indices=np.ascontiguousarray(np.concatenate(idx, 0).astype(np.uint32)), camera=camera,
+                env=environment_synth(), max_depth=5, name="city-synth(blocks=%d,windows=%dx%d,seed=0x%X)" % (blocks, wx, wy, seed))
+
+
+def soup_synth(triangles=1000000, clusters=96, seed=SCENE_SEED ^ 0x50FA, extent=100.0):
+    """Unconnected triangle soup with heavy overlap: no two triangles share a vertex (every pair of the packed scene is a lone triangle
+    with the degenerate second one, Scene.cpp:174-178), sizes log-uniform over 0.05 .. 8, orientations uniform, centres in `clusters`
+    blobs so that hundreds of triangles overlap in the middle of each — the sweep finds no cheap split there and closes LARGE leaves
+    (Bvh2.cpp:462-485), which the kernel's multi-pair leaf loop must walk."""
+    k = np.arange(triangles)
+    cl = (pcg_hash(k ^ seed) % np.uint32(clusters)).astype(np.int64)
+    cc = np.stack([(hash_uniform(np.arange(clusters), 71, seed) * 2 - 1) * extent * 0.85,
+                   5.0 + hash_uniform(np.arange(clusters), 72, seed) * 40.0,
+                   (hash_uniform(np.arange(clusters), 73, seed) * 2 - 1) * extent * 0.85], 1).astype(np.float64)
+    rad = 2.0 + 14.0 * hash_uniform(np.arange(clusters), 74, seed).astype(np.float64)
+    off = np.stack([hash_uniform(k, 75 + a, seed).astype(np.float64) + hash_uniform(k, 78 + a, seed).astype(np.float64) +
+                    hash_uniform(k, 81 + a, seed).astype(np.float64) - 1.5 for a in range(3)], 1)      # ~ gaussian, sigma 0.5
+    ctr = cc[cl] + off * rad[cl][:, None]
+    size = 0.05 * 160.0 ** hash_uniform(k, 84, seed).astype(np.float64)
+    # three random unit offsets around the centre, scaled: slivers included
+    def unit(s0):
+        z = hash_uniform(k, s0, seed).astype(np.float64) * 2 - 1
+        ph = hash_uniform(k, s0 + 1, seed).astype(np.float64) * 2 * np.pi
+        r = np.sqrt(np.maximum(0.0, 1 - z * z))
+        return np.stack([r * np.cos(ph), z, r * np.sin(ph)], 1)
+    tv = np.stack([ctr + unit(85) * size[:, None], ctr + unit(87) * size[:, None], ctr + unit(89) * size[:, None]], 1).reshape(-1, 3)
+    v3 = tv.astype(np.float32)
+    vertices = np.concatenate([v3, np.ones((len(v3), 1), np.float32)], 1)
+    indices = np.arange(3 * triangles, dtype=np.uint32).reshape(-1, 3)
+    camera = dict(origin=np.array([-1.25 * extent, 0.75 * extent, -1.1 * extent], np.float32), target=np.array([0.0, 18.0, 0.0], np.float32),
+                  up=np.array([0.0, 1.0, 0.0], np.float32), fov=55.0)
+    return dict(vertices=np.ascontiguousarray(vertices), indices=np.ascontiguousarray(indices), camera=camera, env=environment_synth(), max_depth=5,
+                name="soup-synth(triangles=%d,clusters=%d,seed=0x%X)" % (triangles, clusters, seed))
+
+
+SCENES = {"battlefield-synth": battlefield_synth, "city-synth": city_synth, "soup-synth": soup_synth}
+
+
 def environment_synth(width=512, height=256):
     """512x256 RGBA32F gradient sky + sun lobe."""
     v, u = np.meshgrid((np.arange(height) + 0.5) / height, (np.arange(width) + 0.5) / width, indexing="ij")

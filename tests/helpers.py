@@ -140,3 +140,149 @@ def comb_scene(height=40):
     while (npad * 3) % 32:
         npad += 1
     return dict(nodes=nodes, pairs=pairs[:npad].copy(), remap=remap, pair_count=n + 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------- hand-made leaves (round 6)
+def _pad_pairs(pairs, count):
+    npad = count
+    while (npad * 3) % 32:                # Scene.cpp:334-338: copies of pair 0 until 3 * count % 32 == 0
+        npad += 1
+    out = np.zeros(npad, orc.PAIR_DTYPE)
+    out[:count] = pairs[:count]
+    out[count:] = pairs[0]
+    return out
+
+
+def quad_pair(a, b, c, d):
+    """The 48-byte record of the pair made of triangles (a, c, b) and (a, d, c) — they share the diagonal a-c, the pair's p0-p1 edge
+    (Scene.cpp:149-153: e1 = p0 - p1, e2 = p2 - p0, e3 = p3 - p0 with p0 = a, p1 = c, p2 = b, p3 = d)."""
+    a, b, c, d = (np.asarray(x, np.float32) for x in (a, b, c, d))
+    rec = np.zeros(1, orc.PAIR_DTYPE)[0]
+    rec["e1"], rec["e2"], rec["p0"] = a - c, b - a, a
+    e3 = d - a
+    rec["e3x"], rec["e3y"], rec["e3z"] = e3
+    return rec
+
+
+def leaf_scene(n_pairs, arrangement="row"):
+    """Hand-made reference-format blobs whose root's LEFT child is ONE leaf of `n_pairs` triangle pairs (the format allows 127,
+    Scene.cpp:294-312; the builder closes leaves of up to 126 triangles, Bvh2.cpp:467-485) and whose right child is a lone far triangle.
+    Pair k is the unit quad [x0, x0+1] x [0, 1] at depth z_k, triangle ids 2k (a, c, b) and 2k+1 (a, d, c) with their index lists rotated so
+    that the edge codes cycle through every value the packer emits (Scene.cpp:132-133: first 0..2, second 1..3) — truthfully: the arbiter,
+    which only sees the triangles, must find the same (u, v).
+      "row"         x0 = 3k, z_k = 10 + (7k mod 5): a ray along +z hits at most one pair
+      "near_first"  x0 = 0,  z_k = 10 + k/2: every pair is hit, the first tested one is the nearest (tFar shrinks once)
+      "near_last"   x0 = 0,  z_k = 10 + (n-1-k)/2: every pair is hit and each one is nearer than the one before (tFar shrinks n times)
+      "coincident"  x0 = 0,  z_k = 10: n exact-distance ties — the reference keeps the LAST one tested (T <= absDet * tFar, Kernels.h:88)
+    Returns (blobs, geometry) with geometry = dict(vertices, indices) for the arbiter."""
+    n = int(n_pairs)
+    assert 1 <= n <= 127
+    pairs = np.zeros(n + 1, orc.PAIR_DTYPE)
+    remap = np.zeros(2 * (n + 1), np.uint32)
+    verts, idx = [], []
+    lo, hi = np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32)
+    for k in range(n):
+        x0 = 3.0 * k if arrangement == "row" else 0.0
+        z = {"row": 10.0 + (7 * k) % 5, "near_first": 10.0 + 0.5 * k, "near_last": 10.0 + 0.5 * (n - 1 - k), "coincident": 10.0}[arrangement]
+        a, b, c, d = [x0, 0, z], [x0 + 1, 0, z], [x0 + 1, 1, z], [x0, 1, z]
+        pairs[k] = quad_pair(a, b, c, d)
+        # the original triangles' index order decides the edge codes (Scene.cpp:127-136): first triangle = (a, c, b) rotated so that a sits at
+        # position e0 (its edge e0 is the shared a->c), second = (c, a, d) rotated so that c sits at position e1 (its edge e1 is c->a)
+        e0, e1 = k % 3, (k // 3) % 3
+        remap[2 * k] = (2 * k) | (e0 << 30)
+        remap[2 * k + 1] = (2 * k + 1) | ((e1 + 1) << 30)
+        base = len(verts)
+        verts += [a, b, c, d]
+        idx += [np.roll([base, base + 2, base + 1], e0).tolist(), np.roll([base + 2, base, base + 3], e1).tolist()]
+        lo = np.minimum(lo, np.array(a, np.float32)); hi = np.maximum(hi, np.array(c, np.float32))
+    # the lone triangle (unpaired: p3 = p1, Scene.cpp:174-178), far off to the side
+    p0, p1, p2 = np.array([-20, 0, 30], np.float32), np.array([-18, 0, 30], np.float32), np.array([-20, 2, 30], np.float32)
+    pairs[n]["e1"], pairs[n]["e2"], pairs[n]["p0"] = p0 - p1, p2 - p0, p0
+    pairs[n]["e3x"], pairs[n]["e3y"], pairs[n]["e3z"] = p1 - p0
+    remap[2 * n] = 2 * n
+    base = len(verts)
+    verts += [p0, p1, p2]
+    idx += [[base, base + 1, base + 2]]
+    nodes = np.zeros(1, orc.GPU_NODE_DTYPE)
+    nodes[0]["kind"] = 1
+    nodes[0]["first"] = (n << 24) | 0
+    nodes[0]["last"] = (1 << 24) | n
+    nodes[0]["leftMin"], nodes[0]["leftMax"] = lo, hi
+    nodes[0]["rightMin"], nodes[0]["rightMax"] = (-20, 0, 30), (-18, 2, 30)
+    v = np.array(verts, np.float32)
+    geometry = dict(vertices=np.concatenate([v, np.ones((len(v), 1), np.float32)], 1), indices=np.array(idx, np.uint32))
+    return dict(nodes=nodes, pairs=_pad_pairs(pairs, n + 1), remap=remap, pair_count=n + 1), geometry
+
+
+def leaf_rays(n_pairs, arrangement):
+    """Rays for leaf_scene: into the first pair, the last, every fifth, between pairs / beside the leaf (no pair), onto the shared diagonal
+    (a tie inside a pair), the lone triangle, tilted ones that cross several pairs' boxes, and a back-face set from behind."""
+    n = int(n_pairs)
+    ks = sorted(set([0, n - 1] + list(range(0, n, 5))))
+    o, d = [], []
+    for k in ks:
+        x0 = 3.0 * k if arrangement == "row" else 0.0
+        for (px, py) in ((0.75, 0.25), (0.25, 0.75), (0.5, 0.5), (0.999, 0.001)):
+            o.append([x0 + px, py, -1.0]); d.append([0, 0, 1])
+            o.append([x0 + px, py, 40.0]); d.append([0, 0, -1])                          # from behind: back faces, reversed test order in depth
+        o.append([x0 + 1.5, 0.5, -1.0]); d.append([0, 0, 1])                              # between two quads of the row / beside the stack: no pair
+        o.append([x0 + 0.5, 0.5, -1.0]); d.append([0.02 * (k % 7 - 3), 0.01, 1])          # tilted
+    o.append([-19.5, 0.5, 0.0]); d.append([0, 0, 1])                                      # the lone triangle
+    o.append([-18.2, 1.8, 0.0]); d.append([0, 0, 1])                                      # ... its phantom second half: a miss
+    o.append([-30.0, 0.5, 12.0]); d.append([1, 0.001, 0.02])                              # along the row, grazing
+    dd = np.array(d, np.float64)
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    return make_rays(o, dd)
+
+
+def sliver_scene(count=3000, seed=77):
+    """Needle triangles whose area goes to zero: length 5 .. 60, width 1e-6 .. 1e-1 (log-uniform), random orientation, no shared
+    vertices, in a 100^3 box — the pair test's determinants lose most of their bits."""
+    k = np.arange(count)
+    ctr = np.stack([(synth.hash_uniform(k, 1, seed) * 2 - 1) * 50, (synth.hash_uniform(k, 2, seed) * 2 - 1) * 50, (synth.hash_uniform(k, 3, seed) * 2 - 1) * 50], 1).astype(np.float64)
+    def unit(s0):
+        z = synth.hash_uniform(k, s0, seed).astype(np.float64) * 2 - 1
+        ph = synth.hash_uniform(k, s0 + 1, seed).astype(np.float64) * 2 * np.pi
+        r = np.sqrt(np.maximum(0.0, 1 - z * z))
+        return np.stack([r * np.cos(ph), z, r * np.sin(ph)], 1)
+    along, side = unit(4), unit(6)
+    side -= along * (side * along).sum(1, keepdims=True)
+    side /= np.linalg.norm(side, axis=1, keepdims=True)
+    length = (5 + 55 * synth.hash_uniform(k, 8, seed).astype(np.float64))[:, None]
+    width = (1e-6 * 1e5 ** synth.hash_uniform(k, 9, seed).astype(np.float64))[:, None]
+    v = np.stack([ctr - along * length * 0.5, ctr + along * length * 0.5, ctr + side * width], 1).reshape(-1, 3).astype(np.float32)
+    return dict(vertices=np.concatenate([v, np.ones((len(v), 1), np.float32)], 1), indices=np.arange(3 * count, dtype=np.uint32).reshape(-1, 3))
+
+
+def far_scene(scale=1000.0, shift=(5e4, 2e4, -7e4)):
+    """The small battlefield-synth scene blown up and moved so that every coordinate sits at 1e4 .. 2e5 (binary32 spacing 0.004 .. 0.016):
+    box planes, origins and the pair test's C = p0 - o all round visibly."""
+    sc = synth.battlefield_synth(grid=40, boxes=32, quads=100)
+    sh = np.array(shift, np.float32)
+    v = sc["vertices"].copy()
+    v[:, :3] = v[:, :3] * np.float32(scale) + sh
+    cam = dict(sc["camera"])
+    cam["origin"] = (np.asarray(cam["origin"], np.float32) * np.float32(scale) + sh).astype(np.float32)
+    cam["target"] = (np.asarray(cam["target"], np.float32) * np.float32(scale) + sh).astype(np.float32)
+    out = dict(sc, vertices=np.ascontiguousarray(v), camera=cam)
+    return out
+
+
+def compare_with_reference_kernel(ref, other, what, rel=1e-4, max_ties=None):
+    """The reference's kernel is built with its own fast-math options (RayAccelerator.cpp:489-490), so it is compared within
+    north_star's tolerance: NO hit/miss disagreement is accepted; a different primId only as a tie (both report the same
+    distance to 1e-5: coplanar or edge-sharing triangles, the later test wins in one arithmetic and not in the other)."""
+    n = len(ref)
+    hit_r, hit_o = ref["triangle"] != MISS, other["triangle"] != MISS
+    disagreements = int((hit_r != hit_o).sum())
+    both = hit_r & hit_o
+    diff = both & (ref["triangle"] != other["triangle"])
+    print("%s: %d rays, %d hit/miss disagreements, %d primId ties" % (what, n, disagreements, int(diff.sum())))
+    assert disagreements == 0, "%s: %d hit/miss disagreements" % (what, disagreements)
+    assert np.allclose(ref["t"][diff], other["t"][diff], rtol=1e-5), "%s: %d primId mismatches that are not ties" % (what, diff.sum())
+    assert diff.sum() <= (max(2, n // 20000) if max_ties is None else max_ties), "%s: %d ties" % (what, diff.sum())
+    same = both & ~diff
+    np.testing.assert_allclose(other["t"][same], ref["t"][same], rtol=rel, err_msg=what)
+    np.testing.assert_allclose(other["u"][same], ref["u"][same], rtol=rel, atol=2e-6, err_msg=what)
+    np.testing.assert_allclose(other["v"][same], ref["v"][same], rtol=rel, atol=2e-6, err_msg=what)
+    return int(diff.sum())

@@ -13,29 +13,12 @@ import pytest
 import rayaccel_amd as ra
 from oracle import oracle as orc, ref_kernel
 from rayaccel_amd import synth
-from helpers import MISS, comb_scene, make_rays
+from helpers import MISS, comb_scene, compare_with_reference_kernel, make_rays
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_kernel.built(), reason="oracle/_ref not built (needs /root/reference at build time)")]
 
 
-def _compare(ref, other, what, rel=1e-4, max_ties=None):
-    """The reference's kernel is built with its own fast-math options (RayAccelerator.cpp:489-490), so it is compared within
-    north_star's tolerance: NO hit/miss disagreement is accepted; a different primId only as a tie (both report the same
-    distance to 1e-5: coplanar or edge-sharing triangles, the later test wins in one arithmetic and not in the other)."""
-    n = len(ref)
-    hit_r, hit_o = ref["triangle"] != MISS, other["triangle"] != MISS
-    disagreements = int((hit_r != hit_o).sum())
-    both = hit_r & hit_o
-    diff = both & (ref["triangle"] != other["triangle"])
-    print("%s: %d rays, %d hit/miss disagreements, %d primId ties" % (what, n, disagreements, int(diff.sum())))
-    assert disagreements == 0, "%s: %d hit/miss disagreements" % (what, disagreements)
-    assert np.allclose(ref["t"][diff], other["t"][diff], rtol=1e-5), "%s: %d primId mismatches that are not ties" % (what, diff.sum())
-    assert diff.sum() <= (max(2, n // 20000) if max_ties is None else max_ties), "%s: %d ties" % (what, diff.sum())
-    same = both & ~diff
-    np.testing.assert_allclose(other["t"][same], ref["t"][same], rtol=rel, err_msg=what)
-    np.testing.assert_allclose(other["u"][same], ref["u"][same], rtol=rel, atol=2e-6, err_msg=what)
-    np.testing.assert_allclose(other["v"][same], ref["v"][same], rtol=rel, atol=2e-6, err_msg=what)
-    return int(diff.sum())
+_compare = compare_with_reference_kernel      # (tests/helpers.py; tests/test_gpu_quality.py and tests/test_gpu_xl.py import it from here)
 
 
 def test_oracle_and_product_match_the_reference_kernel(gpu_ctx, small_scene, small_host):

@@ -14,7 +14,7 @@ import pytest
 
 from oracle import oracle as orc
 from rayaccel_amd import synth
-from helpers import MISS, assert_matches_arbiter, comb_scene, make_rays
+from helpers import MISS, assert_matches_arbiter, comb_scene, far_scene, leaf_rays, leaf_scene, make_rays, sliver_scene
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -155,6 +155,44 @@ def test_kat_leaf_with_126_triangles():
     assert max(leaf_sizes) <= 127
     rays = make_rays([[0.6 * np.cos(a), 0.6 * np.sin(a), -1] for a in ang[::7]], [[0, 0, 1]] * len(ang[::7]))
     assert_matches_arbiter(orc.traverse(blobs, rays), dict(vertices=vv, indices=idx), rays)
+
+
+# ------------------------------------------------- the hand-made scenes of tests/test_gpu_edge_cases.py, oracle vs arbiter (CPU)
+@pytest.mark.parametrize("arrangement", ["row", "near_first", "near_last", "coincident"])
+@pytest.mark.parametrize("n_pairs", [1, 7, 63, 127])
+def test_hand_made_leaves_match_the_arbiter(n_pairs, arrangement):
+    """A leaf of up to 127 pairs (Scene.cpp:294-312) with truthful edge codes: the oracle's (u, v) after the remap rotation
+    (Kernels.h:223-239) are the arbiter's, which only knows the triangles; of n coincident pairs the LAST one tested is kept (Kernels.h:88)."""
+    blobs, geometry = leaf_scene(n_pairs, arrangement)
+    rays = leaf_rays(n_pairs, arrangement)
+    res, nv, npairs, _ = orc.traverse(blobs, rays, counters=True)
+    assert_matches_arbiter(res, geometry, rays)
+    assert npairs.max() == n_pairs and (nv == 1).all()
+    if n_pairs >= 7:
+        assert set((blobs["remap"] >> 30).tolist()) == {0, 1, 2, 3}
+    if arrangement == "coincident":
+        assert res["triangle"][0] // 2 == n_pairs - 1
+
+
+def test_large_coordinates_slivers_and_the_other_scene_classes_match_the_arbiter():
+    far = far_scene()
+    prim, _ = synth.primary_rays(far["camera"], 128, 128)
+    assert np.abs(far["vertices"][:, :3]).max() > 1e5 and np.median(np.abs(far["vertices"][:, :3])) > 1e4
+    assert_matches_arbiter(orc.traverse(orc.build_scene(far["vertices"], far["indices"]), prim), far, prim)
+    sl = sliver_scene()
+    rays = synth.random_rays(20000, seed=3, extent=50.0, ymax=50.0)
+    rays["origin"][:, 1] -= 25
+    res = orc.traverse(orc.build_scene(sl["vertices"], sl["indices"]), rays)
+    assert (res["triangle"] != MISS).sum() > 100
+    assert_matches_arbiter(res, sl, rays, rel=5e-3, uv_atol=1e-2)      # needles of width 1e-6: what the binary32 pair test is good for
+    for sc, min_leaf in ((synth.soup_synth(triangles=12000, clusters=24), 6), (synth.city_synth(blocks=8), 3)):
+        blobs = orc.build_scene(sc["vertices"], sc["indices"])
+        kids = np.concatenate([blobs["nodes"]["first"], blobs["nodes"]["last"]])
+        assert (kids[kids & 0x80000000 == 0] >> 24).max() >= min_leaf
+        prim, _ = synth.primary_rays(sc["camera"], 128, 128)
+        hits = orc.traverse(blobs, prim)
+        rays = np.concatenate([prim[::5], synth.diffuse_bounce_rays(sc, prim, hits, 3000)])
+        assert_matches_arbiter(orc.traverse(blobs, rays), sc, rays, uv_atol=1e-4)
 
 
 def test_deep_stack_comb():
