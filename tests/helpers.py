@@ -224,7 +224,7 @@ def leaf_rays(n_pairs, arrangement):
         x0 = 3.0 * k if arrangement == "row" else 0.0
         for (px, py) in ((0.75, 0.25), (0.25, 0.75), (0.5, 0.5), (0.999, 0.001)):
             o.append([x0 + px, py, -1.0]); d.append([0, 0, 1])
-            o.append([x0 + px, py, 40.0]); d.append([0, 0, -1])                          # from behind: back faces, reversed test order in depth
+            o.append([x0 + px, py, 100.0]); d.append([0, 0, -1])                        # from behind: back faces, reversed test order in depth
         o.append([x0 + 1.5, 0.5, -1.0]); d.append([0, 0, 1])                              # between two quads of the row / beside the stack: no pair
         o.append([x0 + 0.5, 0.5, -1.0]); d.append([0.02 * (k % 7 - 3), 0.01, 1])          # tilted
     o.append([-19.5, 0.5, 0.0]); d.append([0, 0, 1])                                      # the lone triangle
@@ -286,3 +286,39 @@ def compare_with_reference_kernel(ref, other, what, rel=1e-4, max_ties=None):
     np.testing.assert_allclose(other["u"][same], ref["u"][same], rtol=rel, atol=2e-6, err_msg=what)
     np.testing.assert_allclose(other["v"][same], ref["v"][same], rtol=rel, atol=2e-6, err_msg=what)
     return int(diff.sum())
+
+
+def book_scene(k=126):
+    """`k` triangles that ALL have the unit cube as their bounding box — the "pages" of a book around the cube's diagonal: (0,0,0), (1,1,1) and
+    a third vertex on a circle around the diagonal's midpoint — so no sweep position separates them and the builder closes ONE leaf of k
+    triangles (SAH: 2 + k > k; Bvh2.cpp:462-485 forces a split only from 127 on).  No shared vertex indices: k lone pairs.  Plus four far
+    triangles so that the root is an inner node."""
+    e1 = np.array([1.0, -1.0, 0.0]) / np.sqrt(2.0)
+    e2 = np.array([1.0, 1.0, -2.0]) / np.sqrt(6.0)
+    v, idx = [], []
+    for i in range(k):
+        a = 2.0 * np.pi * i / k
+        r = np.array([0.5, 0.5, 0.5]) + 0.4 * (np.cos(a) * e1 + np.sin(a) * e2)
+        v += [[0, 0, 0], [1, 1, 1], r]
+        idx.append([3 * i, 3 * i + 1, 3 * i + 2])
+    for j in range(4):
+        b = len(v)
+        v += [[10 + 3 * j, 0, 0], [11 + 3 * j, 0, 0], [10 + 3 * j, 1, 0]]
+        idx.append([b, b + 1, b + 2])
+    vv = np.concatenate([np.array(v, np.float32), np.ones((len(v), 1), np.float32)], 1)
+    return dict(vertices=vv, indices=np.array(idx, np.uint32))
+
+
+def book_rays(sc, k=126):
+    """At every page's centroid from a point three units out along the page's normal (both sides), plus a fan through the diagonal's midpoint."""
+    v = sc["vertices"][:, :3].astype(np.float64)
+    tri = v[sc["indices"][:k]]
+    c = tri.mean(1)
+    n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    o = np.concatenate([c + 3 * n, c - 3 * n, np.tile([[3.0, -2.0, 0.7]], (40, 1)), [[10.25, 0.25, -1.0], [30.0, 30.0, -1.0]]])
+    t = np.linspace(0.05, 0.95, 40)[:, None]
+    through = np.array([[0.5, 0.5, 0.5]]) + (t - 0.5) * np.array([[0.3, 0.2, -0.6]])
+    d = np.concatenate([-n, n, through - np.array([[3.0, -2.0, 0.7]]), [[0, 0, 1.0], [0, 0, 1.0]]])
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return make_rays(o, d)

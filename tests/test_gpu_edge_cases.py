@@ -8,7 +8,7 @@ allows 127, Scene.cpp:294-312).  Here every case is uploaded through racc_hip_sc
 
   * the default kernel (V8) stand-alone (host path and chain_launches = 2), lazily chained (chain_min_rays = 1: batch after batch
     published to the running kernels, misses shaded by the traversal kernel) and chained with per-launch kernels (chain_launches = 3);
-  * its 8-entry-stack, statistics, inline-probe and LDS-node-cache instantiations (kernel_variant 41, 42, 44, 60-63);
+  * its 8-entry-stack, statistics, inline-probe and LDS-node-cache instantiations (kernel_variant 41, 42, 44, 60-63) and the narrow six-waves-per-SIMD one (70);
   * the 4-wide kernels (45, 46, 48, 49) and the compressed 4-wide ones (50, 51, 53), chained where they have such an instantiation;
   * the reference's own OpenCL kernel on the same blobs (oracle/_ref, where built).
 
@@ -22,7 +22,7 @@ import rayaccel_amd as ra
 from oracle import oracle as orc, ref_kernel
 from rayaccel_amd import synth
 from helpers import (MISS, QUANT_VARIANTS, WIDE_VARIANTS, assert_bit_exact, assert_matches_arbiter, assert_same_closest_hit,
-                     compare_with_reference_kernel, far_scene, leaf_rays, leaf_scene, make_rays, sliver_scene)
+                     book_rays, book_scene, compare_with_reference_kernel, far_scene, leaf_rays, leaf_scene, make_rays, sliver_scene)
 
 pytestmark = pytest.mark.gpu
 
@@ -38,6 +38,8 @@ CONFIGS = {
     "v8 LDS node cache 768 (61)": dict(kernel_variant=61, chain_min_rays=1),
     "v8 LDS node cache 260 (62)": dict(kernel_variant=62, chain_min_rays=1),
     "v8 LDS node cache 128 (63)": dict(kernel_variant=63, chain_min_rays=1),
+    "v8 narrow, six waves per SIMD (70)": dict(kernel_variant=70, chain_min_rays=1),
+    "v8 narrow, stand-alone (70)": dict(kernel_variant=70, chain_launches=2),
     "v9 4-wide (45)": dict(kernel_variant=45),
     "v9 4-wide C++ 6-entry (46)": dict(kernel_variant=46),
     "v9 4-wide C++ (48)": dict(kernel_variant=48),
@@ -162,27 +164,19 @@ def test_kat_edge_codes_rotate_barycentrics(contexts):
     assert codes == {0, 1, 2, 3}
 
 
-def test_kat_leaf_of_126_sliver_triangles_from_the_builder(contexts):
-    """Coincident-centroid slivers cannot be separated by the sweep: the builder closes ONE leaf of 126 triangles (< 127, Bvh2.cpp:467-475),
-    all of them unpaired -> a leaf of 126 pairs with degenerate second triangles, walked by the kernels' multi-pair leaf loop."""
-    k = 126
-    ang = np.linspace(0, np.pi, k, endpoint=False)
-    v, idx = [], []
-    for i, a in enumerate(ang):
-        d = np.array([np.cos(a), np.sin(a), 0.0]); n = np.array([-np.sin(a), np.cos(a), 0.0]); z = i * 1e-3
-        v += [d * 1.0 + [0, 0, z], -d * 0.5 + n * 0.02 + [0, 0, z], -d * 0.5 - n * 0.02 + [0, 0, z]]
-        idx.append([3 * i, 3 * i + 1, 3 * i + 2])
-    vv = np.concatenate([np.array(v, np.float32), np.ones((3 * k, 1), np.float32)], 1)
-    idx = np.array(idx, np.uint32)
-    blobs = orc.build_scene(vv, idx)
-    o = [[0.6 * np.cos(a), 0.6 * np.sin(a), -1] for a in ang] + [[0.6 * np.cos(a), 0.6 * np.sin(a), 1] for a in ang[::3]] + [[0.001, 0.0005, -1], [3, 3, -1]]
-    d = [[0, 0, 1]] * k + [[0, 0, -1]] * len(ang[::3]) + [[0, 0, 1]] * 2
-    rays = make_rays(o, d)
-    kids = np.concatenate([blobs["nodes"]["first"], blobs["nodes"]["last"]])
-    biggest = int((kids[kids & 0x80000000 == 0] >> 24).max())
-    assert biggest >= 60, biggest
-    ref = run_everywhere(contexts, blobs, rays, "126-sliver leaf", min_leaf=biggest, arbiter=dict(vertices=vv, indices=idx))
-    assert_matches_arbiter(ref, dict(vertices=vv, indices=idx), rays)
+def test_kat_leaf_of_126_triangles_from_the_builder(contexts):
+    """126 triangles with one common bounding box cannot be separated by the sweep: the builder closes ONE leaf of 126 triangles (a split is
+    forced only from 127 on, Bvh2.cpp:462-485), all of them unpaired -> a leaf of 126 pairs with degenerate second triangles, walked by the
+    kernels' multi-pair leaf loop; with 127 triangles the forced median split gives leaves of 63 and 64.  Built by the PRODUCT's builder."""
+    for k, biggest in ((126, 126), (127, 64)):
+        sc = book_scene(k)
+        host = ra.HostScene(sc["vertices"], sc["indices"], quality=0)
+        blobs = orc.build_scene(sc["vertices"], sc["indices"])
+        assert host.nodes.tobytes() == blobs["nodes"].tobytes() and host.pairs.tobytes() == blobs["pairs"].tobytes()
+        rays = book_rays(sc, k)
+        ref = run_everywhere(contexts, host.blobs(), rays, "book of %d pages" % k, min_leaf=biggest, arbiter=sc)
+        assert (ref["triangle"] != MISS).sum() >= len(rays) - 2
+        assert_matches_arbiter(ref, sc, rays)
 
 
 # ------------------------------------------------------------------------------------------------------------------------------- big leaves
@@ -197,9 +191,9 @@ def test_hand_made_leaves(contexts, n_pairs, arrangement):
     ref = run_everywhere(contexts, blobs, rays, "leaf of %d pairs, %s" % (n_pairs, arrangement), min_leaf=n_pairs, arbiter=geometry)
     assert_matches_arbiter(ref, geometry, rays)
     first = ref["triangle"][0]
-    assert first != MISS and first // 2 == {"row": 0, "near_first": 0, "near_last": 0, "coincident": n_pairs - 1}[arrangement]
+    assert first != MISS and first // 2 == {"row": 0, "near_first": 0, "near_last": n_pairs - 1, "coincident": n_pairs - 1}[arrangement]
     if arrangement == "near_last" and n_pairs > 1:
-        assert ref["t"][0] == 11.0 and ref["triangle"][1] // 2 == n_pairs - 1      # from behind (ray 1) the LAST pair is the nearest
+        assert ref["t"][0] == 11.0 and ref["triangle"][1] // 2 == 0      # from the front the LAST pair tested is the nearest (tFar shrank n times); from behind (ray 1) the first
 
 
 def test_leaf_of_127_lone_triangles_through_the_packer(contexts):

@@ -14,7 +14,7 @@ import pytest
 
 from oracle import oracle as orc
 from rayaccel_amd import synth
-from helpers import MISS, assert_matches_arbiter, comb_scene, far_scene, leaf_rays, leaf_scene, make_rays, sliver_scene
+from helpers import MISS, assert_matches_arbiter, book_rays, book_scene, comb_scene, far_scene, leaf_rays, leaf_scene, make_rays, sliver_scene
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -137,24 +137,22 @@ def test_kat_edge_codes_rotate_barycentrics():
 
 
 def test_kat_leaf_with_126_triangles():
-    """Coincident-centroid triangles cannot be separated by SAH -> one big leaf (< 127, Bvh2.cpp:467-475)."""
-    k = 126
-    ang = np.linspace(0, np.pi, k, endpoint=False)
-    v, idx = [], []
-    for i, a in enumerate(ang):   # thin slivers through the origin, all with centroid ~ (0,0,i*1e-3)
-        d = np.array([np.cos(a), np.sin(a), 0.0])
-        n = np.array([-np.sin(a), np.cos(a), 0.0])
-        z = i * 1e-3
-        v += [d * 1.0 + [0, 0, z], -d * 0.5 + n * 0.02 + [0, 0, z], -d * 0.5 - n * 0.02 + [0, 0, z]]
-        idx.append([3 * i, 3 * i + 1, 3 * i + 2])
-    vv = np.concatenate([np.array(v, np.float32), np.ones((3 * k, 1), np.float32)], 1)
-    idx = np.array(idx, np.uint32)
-    nodes, _ = orc.bvh2_build(vv, idx)
-    blobs = orc.build_scene(vv, idx)
-    leaf_sizes = [(c >> 24) for c in np.concatenate([blobs["nodes"]["first"], blobs["nodes"]["last"]]) if not c & 0x80000000]
-    assert max(leaf_sizes) <= 127
-    rays = make_rays([[0.6 * np.cos(a), 0.6 * np.sin(a), -1] for a in ang[::7]], [[0, 0, 1]] * len(ang[::7]))
-    assert_matches_arbiter(orc.traverse(blobs, rays), dict(vertices=vv, indices=idx), rays)
+    """126 triangles that all have the same bounding box cannot be separated by the sweep -> ONE leaf of 126 triangles (the estimate says leaf,
+    and only from 127 triangles on is a split forced: Bvh2.cpp:462-485) = 126 lone pairs; with 127 the forced median split gives 63 + 64.
+    (Until round 5 this test built slivers with coincident centroids, which the sweep does separate: its largest leaf held 11 pairs.)"""
+    sc = book_scene(126)
+    blobs = orc.build_scene(sc["vertices"], sc["indices"])
+    leaf_sizes = sorted((c >> 24) for c in np.concatenate([blobs["nodes"]["first"], blobs["nodes"]["last"]]) if not c & 0x80000000)
+    assert leaf_sizes[-1] == 126
+    rays = book_rays(sc)
+    res, _, npairs, _ = orc.traverse(blobs, rays, counters=True)
+    assert npairs.max() == 126 and (res["triangle"] != MISS).sum() >= len(rays) - 2
+    assert_matches_arbiter(res, sc, rays)
+    forced = book_scene(127)
+    fb = orc.build_scene(forced["vertices"], forced["indices"])
+    sizes = sorted((c >> 24) for c in np.concatenate([fb["nodes"]["first"], fb["nodes"]["last"]]) if not c & 0x80000000)
+    assert sizes[-2:] == [63, 64]
+    assert_matches_arbiter(orc.traverse(fb, book_rays(forced, 127)), forced, book_rays(forced, 127))
 
 
 # ------------------------------------------------- the hand-made scenes of tests/test_gpu_edge_cases.py, oracle vs arbiter (CPU)
