@@ -184,6 +184,10 @@ int racc_hip_intersect(racc_hip_ctx* ctx, const racc_hip_scene* scene, const rac
  * The host arrays belong to the engine until racc_hip_wait on the lane (or RACC_HIP_LANE_AUTO: every lane) has returned. */
 int racc_hip_intersect_async(racc_hip_ctx* ctx, const racc_hip_scene* scene, const racc_hip_env* env,
                              const void* rays, void* results, uint32_t count, uint32_t lane);
+/* racc_hip_wait(lane): the lane's host batch is copied out / its device-resident launches have ended.  With chained launches (the default
+ * for device-resident batches of >= chain_min_rays rays) a batch is complete when its chain is, whichever lane it was issued on: while a
+ * chain has batches outstanding, a wait for ONE lane waits for every lane's kernels (a context-wide wait) and holds the chain's mutex
+ * meanwhile — threads that each drive a lane of their own and wait often should create the context with chain_launches = 2. */
 int racc_hip_wait(racc_hip_ctx* ctx, uint32_t lane);
 
 /* MI355X-sized dispatch: a whole set of ray streams in ONE launch.  The reference launches once per

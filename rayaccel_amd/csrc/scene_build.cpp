@@ -365,12 +365,17 @@ public:
                 stack.push_back(n_[i].last); stack.push_back(n_[i].first);
             }
             if (roots.size() == 1 && roots[0] == root) { Sub s(n_, root); s.optimise(ph.passes, ph.fraction, ph.maxCandidates); root = s.root; continue; }
+            std::vector<int> slots(roots.size());      // (sequential: nothing runs yet)
+            for (size_t k = 0; k < roots.size(); ++k) {
+                const uint32_t up = n_[roots[k]].parent;
+                slots[k] = up == 0xFFFFFFFFu ? -1 : (n_[up].first == roots[k] ? 0 : 1);
+            }
             std::atomic<size_t> next{0};
             auto work = [&]() {
                 for (;;) {
                     const size_t k = next.fetch_add(1);
                     if (k >= roots.size()) return;
-                    Sub s(n_, roots[k]);
+                    Sub s(n_, roots[k], slots[k]);
                     s.optimise(ph.passes, ph.fraction, ph.maxCandidates);
                 }
             };
@@ -421,7 +426,10 @@ private:
         std::vector<Entry> heap;
         std::vector<std::pair<float, uint32_t>> cand;
         std::vector<uint32_t> stack;
-        Sub(Bvh2Node* nodes, uint32_t r) : n(nodes), root(r) {}
+        int outerSlot = -1;      // which child slot of the node ABOVE the subtree points at it (0 first, 1 last); -1: look (whole tree / sequential use).  Set before the
+                                 // parallel phases start: two sibling subtrees hang off one parent, and "is it .first?" asked by one thread while the other
+                                 // writes .first is a data race (benign on x86 — neither value equals the reader's Y — but one all the same)
+        Sub(Bvh2Node* nodes, uint32_t r, int slot = -1) : n(nodes), root(r), outerSlot(slot) {}
 
         static bool later(const Entry& a, const Entry& b) { return a.induced > b.induced || (a.induced == b.induced && a.node > b.node); }
 
@@ -473,7 +481,10 @@ private:
             Bvh2Node& f = n[freeNode];
             const uint32_t above = n[Y].parent;
             f.kind = 1; f.parent = above; f.first = Y; f.last = X;
-            if (above != 0xFFFFFFFFu) { if (n[above].first == Y) n[above].first = freeNode; else n[above].last = freeNode; }
+            if (above != 0xFFFFFFFFu) {
+                if (Y == root && outerSlot >= 0) { if (outerSlot == 0) n[above].first = freeNode; else n[above].last = freeNode; }      // the one link out of the subtree: written, never read
+                else if (n[above].first == Y) n[above].first = freeNode; else n[above].last = freeNode;
+            }
             n[Y].parent = freeNode; n[X].parent = freeNode;
             for (int k = 0; k < 3; ++k) { f.bbMin[k] = std::min(n[Y].bbMin[k], n[X].bbMin[k]); f.bbMax[k] = std::max(n[Y].bbMax[k], n[X].bbMax[k]); }
             if (Y == root) root = freeNode;      // (same leaf set below: same box as the old root's)

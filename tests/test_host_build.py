@@ -185,6 +185,17 @@ def test_group_workers_under_thread_sanitizer(tsan_builds):
     assert p.returncode == 0 and "ThreadSanitizer" not in p.stderr, p.stdout + p.stderr[-3000:]
 
 
+def test_scene_build_under_thread_sanitizer(tsan_builds):
+    """The host scene build — the thread-pool BVH2 build and the quality mode's parallel subtree phases (sibling subtrees share the node
+    above them: ADVICE r05) — under -fsanitize=thread (`make tsan`, tests/cpp/scene_build_tsan.cpp): no race, and the blobs of a 6-thread
+    build equal those of a 1-thread build."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "scene_build_tsan")
+    assert os.path.exists(exe), "make -C rayaccel_amd/csrc tsan"
+    p = subprocess.run([exe, "96", "6"], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66"))
+    assert p.returncode == 0 and "ThreadSanitizer" not in p.stderr, p.stdout + p.stderr[-3000:]
+
+
 def _device_to_reference(dev):
     """64 B device records (racc_host_scene_device_nodes) back into the reference's node format (Scene.cpp:73-78)."""
     out = np.zeros(len(dev), ra.engine.GPU_NODE_DTYPE)
