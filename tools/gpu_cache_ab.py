@@ -20,6 +20,24 @@ ref = orc.traverse(host.blobs(), prim, threads=16)
 sets = [synth.diffuse_bounce_rays(sc, prim, ref, 1 << 20, first_sample=s) for s in range(4)]
 diff = np.concatenate(sets)
 base = {}
+
+
+def same(out, ref_bytes, v, name, row):
+    """Byte-identical to the first variant's records — except for the 4-wide kernels (kernel_variant 45-53), which may differ on exact-distance
+    ties and arbiter-confirmed closer hits (tests/helpers.py::assert_same_closest_hit holds them to that in the suite): there the number of
+    differing records is reported and bounded."""
+    if out.tobytes() == ref_bytes:
+        return
+    kv = v.get("kernel_variant", 0) if isinstance(v, dict) else v
+    assert 45 <= kv <= 53, "%s differs on %s" % (v, name)
+    ref = np.frombuffer(ref_bytes, orc.RESULT_DTYPE)
+    n = int((out.view(np.uint8).reshape(-1, 16) != ref.view(np.uint8).reshape(-1, 16)).any(1).sum())
+    hit = ref["triangle"] != 0xFFFFFFFF
+    n_hit = int(((out.view(np.uint8).reshape(-1, 16) != ref.view(np.uint8).reshape(-1, 16)).any(1) & hit).sum())
+    row.setdefault("records_differing_from_first", {})[name] = [n_hit, n - n_hit]      # [hit records, miss records (colours to rounding)]
+    assert n_hit <= max(4, len(ref) // 100000), "%s: %d hit records differ on %s" % (v, n_hit, name)
+
+
 variants = [json.loads(v) for v in args] or [{}, {"waves_per_simd": 4}, 60, 61, 62, 63]      # an int = kernel_variant, a dict = Context options
 for v in variants:
     with ra.Context(device=0, **(v if isinstance(v, dict) else dict(kernel_variant=v))) as ctx:
@@ -33,7 +51,7 @@ for v in variants:
             row[name] = round(float(np.median(ms)), 4)
             out = d_o.download(orc.RESULT_DTYPE, n)
             if name in base:
-                assert out.tobytes() == base[name], "%s differs on %s" % (v, name)
+                same(out, base[name], v, name, row)
             else:
                 base[name] = out.tobytes()
             d_r.free(); d_o.free()
@@ -58,7 +76,7 @@ for v in variants:
             out = d_outs[(96 + k) % 8].download(orc.RESULT_DTYPE, 1 << 20)
             key = "set%d" % k
             if key in base:
-                assert out.tobytes() == base[key], "%s differs on chained %s" % (v, key)
+                same(out, base[key], v, "chained " + key, row)
             else:
                 base[key] = out.tobytes()
         info = ctx.launch_info(0) if hasattr(ctx, "launch_info") else None
