@@ -46,6 +46,14 @@ GpuContext gpuContextForDevice(int ordinal);
 // place — no exchange between GPUs on this path.  `ordinals` may repeat an entry (two engine contexts on one GPU: rehearsal).
 GpuContext gpuContextForDevices(const int* ordinals, unsigned count);
 GpuContext gpuContextForAllDevices();
+// Fast traversal mode (opt-in; no counterpart in the reference; default off).  Contexts created from this handle trace with the compressed
+// 4-wide kernel (racc_hip_options::kernel_variant 50: half the node bytes per ray, 6-15 % more rays per second).  What changes for the
+// caller: the reported hit is still the closest hit by SURVEY.md §8(c)'s acceptance rule — the double-precision arbiter's — but where two
+// triangles are hit at EXACTLY the same distance (a shared edge or vertex) `triangle` may be the other one than the reference's traversal
+// order would report, and a hit the reference's own box test culls although its pair test accepts it is reported (the closer one).
+// t, u, v of a reported triangle are computed by the reference's pair test, bit for bit.  The environment variable RACC_FAST_TRAVERSAL=1/0
+// overrides the handle's setting for every context the process creates.
+void setFastTraversal(GpuContext gpuContext, bool on);
 
 struct Configuration {                                   // reference :32-42
     GpuContext gpuContext;

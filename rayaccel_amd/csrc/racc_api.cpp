@@ -41,6 +41,7 @@ namespace racc {
 struct GpuContextTag {
     uint32_t count;
     int ordinals[RACC_MAX_DEVICES];
+    bool fastTraversal = false;      // setFastTraversal: contexts created from this handle run the compressed 4-wide kernel (racc_hip_options::kernel_variant 50)
 };
 
 struct Scene {
@@ -334,6 +335,8 @@ GpuContext gpuContextForDevices(const int* ordinals, unsigned count) {
 
 GpuContext gpuContextForDevice(int ordinal) { return gpuContextForDevices(&ordinal, 1); }
 
+void setFastTraversal(GpuContext gpuContext, bool on) { if (gpuContext) gpuContext->fastTraversal = on; }
+
 GpuContext gpuContextForAllDevices() {
     int n = 0;
     if (racc_hip_device_count(&n) != RACC_HIP_OK || n <= 0) return nullptr;
@@ -382,6 +385,10 @@ Context* createContext(Configuration cfg) {
     racc_hip_options opts{};
     opts.struct_size = sizeof(opts);
     opts.lanes = (cfg.gpuSubmissionThreads + nDev - 1) / nDev;
+    {   // fast mode (opt-in, racc::setFastTraversal or RACC_FAST_TRAVERSAL=1): the compressed 4-wide kernel.  Default: the bit-exact one.
+        const char* e = std::getenv("RACC_FAST_TRAVERSAL");
+        if (e ? std::atoi(e) != 0 : cfg.gpuContext->fastTraversal) opts.kernel_variant = 50;
+    }
     for (unsigned d = 0; d < nDev; ++d) {
         racc_hip_ctx* hip = nullptr;
         if (racc_hip_create(cfg.gpuContext->ordinals[d], &opts, &hip) != RACC_HIP_OK) {

@@ -59,6 +59,20 @@ def test_render_matches_oracle(tmp_path, small_scene, small_host, small_default_
         np.testing.assert_allclose(got[f][~hit], ref[f][~hit], rtol=1e-5, atol=1e-5)
 
 
+def test_fast_traversal_mode_through_render(tmp_path, small_scene, small_default_host):
+    """racc::setFastTraversal / RACC_FAST_TRAVERSAL=1: racc::render on the compressed 4-wide kernel (kernel_variant 50).  Every traced ray
+    re-traced by the oracle: the same closest hit, bit for bit, except exact-distance ties and arbiter-confirmed closer hits
+    (tests/helpers.py::assert_same_closest_hit) — the documented contract of the opt-in mode; the default stays bit-exact."""
+    from helpers import assert_same_closest_hit
+    info, recs = _run(str(tmp_path), small_scene, 512, 384, 3, frames=1, env=dict(RACC_FAST_TRAVERSAL="1"))
+    rays = np.ascontiguousarray(recs["ray"])
+    ref = orc.traverse(small_default_host.blobs(), rays, env=small_scene["env"], threads=8)
+    differing = assert_same_closest_hit(np.ascontiguousarray(recs["res"]), ref, "fast traversal through racc::render",
+                                        arbiter=dict(vertices=small_scene["vertices"], indices=small_scene["indices"], rays=rays))
+    print("fast traversal: %d of %d records differ from the oracle (ties / arbiter-confirmed closer hits)" % (differing, len(rays)))
+    assert len(recs) > 3 * 128 * 128
+
+
 def _check_against_oracle(recs, blobs, env):
     ref = orc.traverse(blobs, np.ascontiguousarray(recs["ray"]), env=env, threads=8)
     got = np.ascontiguousarray(recs["res"])
