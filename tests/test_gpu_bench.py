@@ -23,17 +23,52 @@ def _line(cmd, env=None):
 
 
 def test_single_gpu_line():
-    d = _line([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--grid", "128", "--no-extras"])
+    d = _line([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--grid", "128", "--no-extras", "--gather"])
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["unit"] == "Mrays/s"
     assert d["value"] > 0 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r)        # the measurement contract's keys
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["kernel_ms_avg"] > 0
-    # achieved = algorithmic bytes (oracle counters, live) / the kernel's isolated launch duration (HIP events); frac = achieved / peak
+    # round 6: `bound` names what binds on this cache-resident scene — the CU gather path, against its MEASURED ceiling — and no `frac` exceeds 1;
+    # the HBM yard-stick is carried beside it (hbm_algorithmic_frac may exceed 1: the bytes never cross the fabric, hbm_traffic_frac says how few do)
+    assert r["bound"] == "cu_gather_path" and r["unit"] == "GB/s" and r["kernel_ms_avg"] > 0 and 15000 < r["peak"] < 40000
     assert r["algorithmic_bytes_per_launch"] > 0 and abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e9) < 0.01 * r["achieved"]
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["timed_region"]["ms_per_step"] == d["ms_per_step"]
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1 and r["timed_region"]["ms_per_step"] == d["ms_per_step"]
+    assert r["hbm_peak_gbs"] == 8000.0 and abs(r["hbm_algorithmic_frac"] - r["achieved"] / 8000.0) < 1e-3
+
+    def fracs(o, path="line"):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if k == "frac" and v is not None:
+                    assert v <= 1.0, "%s.frac = %r" % (path, v)
+                fracs(v, path + "." + k)
+    fracs(d)
+    assert d["cpu_baseline"]["kind"] in ("port", "simd-port") and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    # the scene is built exactly as racc::createScene builds it: racc_host_scene_build without options = the library default (quality 1)
+    assert "racc::createScene" in d["config"]["scene_build"] and d["config"]["tree"].startswith("quality 1:")
+    import rayaccel_amd as ra
+    from rayaccel_amd import synth
+    sc = synth.battlefield_synth(grid=128, boxes=128 * 6, quads=128 * 28)
+    default = ra.HostScene(sc["vertices"], sc["indices"], quality=None)
+    assert default.quality == 1 and ("%d inner nodes, %d pairs" % (len(default.nodes), default.pair_count)) in d["config"]["tree"]
+    # the K steps with the all-gather of every step's hit records, serialised and overlapped — at N = 1 RCCL with one rank (the plumbing)
+    g = d["with_allgather_of_results_overlapped"]
+    assert "error" not in g, g
+    assert g["ranks"] == 1 and g["mrays_per_s"] > 0 and g["own_shard_in_the_gathered_array_equals_the_timed_results"] is True
+    assert d["with_allgather_of_results"]["mrays_per_s"] > 0 and g["bytes_gathered_per_step"] == 16 << 20
+
+
+def test_other_scene_classes_and_a_scene_file(tmp_path):
+    """bench.py --scene city-synth / soup-synth and --scene-file (the reference's .bin layout, Renderer/main.cpp:117-191: where the real battlefield.bin
+    drops in): the line is produced, every timed record is held to the oracle inside the run (bench.py refuses to print otherwise)."""
+    from rayaccel_amd import synth
+    for extra in (["--scene", "city-synth"], ["--scene", "soup-synth"]):
+        d = _line([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--grid", "96", "--no-extras"] + extra)
+        assert d["value"] > 0 and extra[1] in d["config"]["scene"] and d["config"]["node_visits_per_ray"] > 1 and d["cpu_baseline"]["value"] > 0
+    path = os.path.join(str(tmp_path), "scene.bin")
+    synth.write_scene_bin(path, synth.battlefield_synth(grid=64, boxes=100, quads=400))
+    d = _line([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-extras", "--scene-file", path])
+    assert d["value"] > 0 and d["config"]["scene"] == "file:scene.bin" and d["data"].startswith("scene file")
 
 
 def test_two_ranks_rehearsal():
