@@ -379,11 +379,16 @@ def main():
         # (without these figures) and every rank leaves.
         import threading
         wd = None
+        # (RCCL prints a version banner on STDOUT when its first communicator comes up: stdout is pointed at stderr for the duration — the
+        #  line is the only thing this command prints there)
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         if world > 1:
             def give_up_gather():
                 if rank == 0:
                     line["with_allgather_of_results_overlapped"] = {"error": "the all-gather extras did not finish within %s s: line printed without them" % os.environ.get("RACC_BENCH_GATHER_EXTRA_TIMEOUT", "180")}
-                    print(json.dumps(line), flush=True)
+                    os.write(real_stdout, (json.dumps(line) + "\n").encode())
                 os._exit(0 if rank == 0 else 3)
             wd = threading.Timer(float(os.environ.get("RACC_BENCH_GATHER_EXTRA_TIMEOUT", "180")), give_up_gather)
             wd.daemon = True
@@ -394,6 +399,11 @@ def main():
             extras["with_allgather_of_results_overlapped"] = {"error": str(e)[:300]}
         if wd:
             wd.cancel()
+        sys.stdout.flush()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # (the banner sits in C stdio's buffer — a pipe is fully buffered — and would come out at exit, behind the line)
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
     # (N > 1: no other untimed extras — rank 0 would still be measuring while the other ranks tear the process group down)
     if rank == 0 and world == 1 and not args.no_extras:
         extras.update(bx.single_gpu_extras(S))
