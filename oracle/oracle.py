@@ -27,7 +27,7 @@ assert BVH2_NODE_DTYPE.itemsize == 48 and GPU_NODE_DTYPE.itemsize == 64 and PAIR
 def build(force=False):
     """Compile oracle/libracc_oracle.so with gcc (building the checker is not using it)."""
     src = os.path.join(_HERE, "racc_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "racc_oracle_simd.c"))):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libracc_oracle.so"])
     # oracle/_ref: the reference's own traversal kernel, built only where /root/reference exists (this container)
     subprocess.call(["make", "-s", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -52,6 +52,9 @@ def lib():
         _lib.orc_traverse.restype = None
         _lib.orc_traverse_mt.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, u32, u32, u32, u32]
         _lib.orc_traverse_mt.restype = None
+        _lib.orc_traverse_simd_mt.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, u32, u32, u32, u32]
+        _lib.orc_traverse_simd_mt.restype = None
+        _lib.orc_simd_available.restype = C.c_int
         _lib.orc_env_sample.argtypes = [vp, u32, u32, vp, vp]
         _lib.orc_env_sample.restype = None
         _lib.orc_brute_closest.argtypes = [vp, vp, u32, vp, u32, vp, vp, vp, vp, vp]
@@ -146,6 +149,27 @@ def traverse(scene, rays, env=None, counters=False, threads=1, repeat=1, out=Non
         lib().orc_traverse_mt(_p(nodes), _p(pairs), _p(remap), envp, w, h, _p(rays), _p(out), n, 1024, threads, repeat)
     else:
         lib().orc_traverse(_p(nodes), _p(pairs), _p(remap), envp, w, h, _p(rays), _p(out), 0, n, None, None, None)
+    return out
+
+
+def simd_available():
+    """The host has AVX2 + FMA (racc_oracle_simd.c needs them)."""
+    return bool(lib().orc_simd_available())
+
+
+def traverse_simd(scene, rays, env=None, threads=1, repeat=1, out=None):
+    """orc_traverse eight rays at a time in AVX2 (racc_oracle_simd.c): bit-identical to traverse(); bench.py's cpu_baseline kind "simd-port"."""
+    rays = np.ascontiguousarray(rays)
+    assert rays.dtype == RAY_DTYPE
+    n = len(rays)
+    if out is None:
+        out = np.zeros(n, RESULT_DTYPE)
+    envp, w, h = None, 0, 0
+    if env is not None:
+        env = np.ascontiguousarray(env, dtype=np.float32)
+        h, w = env.shape[0], env.shape[1]
+        envp = _p(env)
+    lib().orc_traverse_simd_mt(_p(scene["nodes"]), _p(scene["pairs"]), _p(scene["remap"]), envp, w, h, _p(rays), _p(out), n, 1024, threads, repeat)
     return out
 
 

@@ -90,6 +90,17 @@ void orc_traverse_mt(const orc_gpu_node* nodes, const orc_pair* pairs, const uin
                      const orc_ray* rays, orc_result* results, uint32_t count,
                      uint32_t slice, uint32_t threads, uint32_t repeat);
 
+/* racc_oracle_simd.c — the same traversal eight rays at a time in AVX2 (every lane does what orc_traverse does for its ray: results are
+ * bit-identical; the reference hands its CPU leg 8 rays at a time, Scene.cpp:386-428).  bench.py's cpu_baseline kind "simd-port". */
+int orc_simd_available(void);
+void orc_traverse_simd(const orc_gpu_node* nodes, const orc_pair* pairs, const uint32_t* remap,
+                       const float* env, uint32_t envW, uint32_t envH,
+                       const orc_ray* rays, orc_result* results, uint32_t start, uint32_t end);
+void orc_traverse_simd_mt(const orc_gpu_node* nodes, const orc_pair* pairs, const uint32_t* remap,
+                          const float* env, uint32_t envW, uint32_t envH,
+                          const orc_ray* rays, orc_result* results, uint32_t count,
+                          uint32_t slice, uint32_t threads, uint32_t repeat);
+
 /* Kernels.h:213-222 — miss colour for a (clamped) direction; OpenCL
  * CLK_NORMALIZED_COORDS_TRUE | CLAMP_TO_EDGE | FILTER_LINEAR semantics. */
 void orc_env_sample(const float* env, uint32_t envW, uint32_t envH, const float dir[3], float rgb[3]);
