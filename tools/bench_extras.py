@@ -173,7 +173,7 @@ def single_gpu_extras(S):
     if not np.array_equal(res_host.view(np.uint32).reshape(-1, 4), S.d_ref_bits.cpu().numpy().view(np.uint32)):
         sys.exit("bench: the host-buffer path changed the results")
     # ... and page-locked arrays the way a host application binds the C-ABI: tools/host_path_bench.py in a process of its own, without torch
-    # (torch ships its own, older HIP runtime; with it loaded the same pipeline moves 40-47 instead of 54 GB/s into the GPU: tools/gpu_hostpipe.py)
+    # (torch ships its own, older HIP runtime; with it loaded the same pipeline moves 40-47 instead of 54 GB/s into the GPU: measured both ways in round 4)
     if S.standard_scene:
         try:
             p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_path_bench.py"), "--grid", str(args.grid), "--device", str(S.device),

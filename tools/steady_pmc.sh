@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 5: what binds the kernel in STEADY STATE.  profiles/r05/derived.json describes an isolated 1M-ray launch, a third of which is ramp-up and
+# What binds the kernel in STEADY STATE (round 5).  profiles/<round>/derived.json describes an isolated 1M-ray launch, a third of which is ramp-up and
 # drain; here the same counters for 8M-ray launches (bench.py --mode strong at N = 1: one 8M-ray batch per step, one lane, no chaining — a launch
 # is 1.65 ms, of which ramp-up and drain are ~8 %).  One rocprofv3 --pmc run per counter set (tools/pmc_probe.sh), condensed with
-# tools/summarize_profile.py's formulas into gpurun_out/steady_state_pmc.json (committed as profiles/r05/steady_state_pmc.json).
+# tools/summarize_profile.py's formulas into gpurun_out/steady_state_pmc.json (tools/summarize_profile.py copies it into profiles/<round>/).
 cd "${GRAFT_REPO_ROOT:-.}"
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export RACC_BENCH_ISO_LAUNCHES=0

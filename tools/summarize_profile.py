@@ -13,7 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CUS, SIMDS, XCDS = 256, 1024, 8
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
@@ -172,6 +172,12 @@ for key in ("diffuse", "coherent", "v10_diffuse", "xl", "xl_diffuse", "q0_diffus
 cx = pm["diffuse_chained"]
 if cx.get("FETCH_SIZE") and cx.get("WRITE_SIZE"):
     der["diffuse"]["fabric_bytes_per_step_chained"] = int((2 * cx["FETCH_SIZE"]["mean_timed"] + cx["WRITE_SIZE"]["mean_timed"]) * 1024.0)
+# round 6: the instantiation that is actually TIMED — lazily chained, misses shaded in the kernel — from the pmcx passes (default options).  Counters
+# are per step (summed over the chain's kernels / 20: under --pmc rocprofv3 serialises dispatches, the chain's first kernel works through all 20
+# batches); the kernel name and the per-step span come from the chained kernel trace (`stats`).
+ct = out.get("kernel_trace") or {}
+der["diffuse_chained"] = derive(cx, dict(kernel=ct.get("kernel"), timed_mean_ms=ct.get("timed_span_ms_per_launch")))
+der["diffuse_chained"]["what"] = "per step of the lazily chained timed region (sum over the chain's kernels / 20); kernel_ms_isolated here = the span of the chain's kernels / 20 in the kernel-trace pass"
 d0, d1 = der["diffuse"], der["v10_diffuse"]
 if d0.get("SQ_INSTS_VMEM_RD_per_launch") and d1.get("SQ_INSTS_VMEM_RD_per_launch"):
     der["v10_vs_default"] = dict(vmem_rd_insts=round(d1["SQ_INSTS_VMEM_RD_per_launch"] / d0["SQ_INSTS_VMEM_RD_per_launch"], 3),
@@ -188,7 +194,7 @@ der["tree"] = "diffuse / coherent / v10_diffuse / xl / xl_diffuse: racc_host_bui
 # the means in derived.json are over the 20 timed dispatches only — listed here so that they can be recomputed from a committed file
 json.dump(dict(what="durations in ms of the last 20 traversal dispatches of each kernel-trace pass (= the 20 timed steps)", passes=TIMED),
           open(os.path.join(dst, "timed_dispatches.json"), "w"), indent=1)
-for extra in ("step_stats.json",):
+for extra in ("step_stats.json", "steady_state_pmc.json"):
     if os.path.exists(os.path.join(ROOT, "gpurun_out", extra)):
         shutil.copy(os.path.join(ROOT, "gpurun_out", extra), os.path.join(dst, extra))
 json.dump(der, open(os.path.join(dst, "derived.json"), "w"), indent=1)
