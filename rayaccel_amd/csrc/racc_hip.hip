@@ -166,15 +166,7 @@ struct racc_hip_ctx {
     // established when somebody waits (finishChain): every chain kernel has ended and every published batch's cursor has passed its count;
     // a batch the chain did not reach (its kernels ended before the link landed) gets a catch-up kernel there.
     bool chainLazy = true;
-    struct ChainLive { hipEvent_t end; uint32_t chainId; uint32_t drainSlot; };
-    // Drain tracking (round 6): a chain kernel counts as one of the chain's kernels while its end event has not fired AND fewer than three
-    // quarters of its workgroups have ended.  A kernel in its drain is alive with a few long-ray waves only; a batch published to it alone
-    // would be traced by those few waves (a caller issuing batches at about the GPU's pace: tests/test_gpu_edge_cases.py::test_paced_issue...).
-    // hostTrips words [kDrainBase, kDrainBase + kDrainRing): one flag per chain kernel in rotation, set by the kernel (TraverseArgs::drainFlag);
-    // chainDrainCounts: the device words its workgroups count in (self-resetting: atomicInc wraps to 0 with the last workgroup).
-    static constexpr uint32_t kDrainBase = 64, kDrainRing = 256;
-    uint32_t* chainDrainCounts = nullptr;
-    uint32_t chainDrainHead = 0;
+    struct ChainLive { hipEvent_t end; uint32_t chainId; };
     std::vector<ChainLive> chainLive;    // chain kernels launched and not yet seen ended
     std::vector<hipEvent_t> chainEventPool;
     uint32_t chainId = 0;                // bumped at every chain start (a launch with no predecessor to link behind)
@@ -301,8 +293,8 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
         if (e3 != hipSuccess) { racc_hip_destroy(ctx); return fail(RACC_HIP_ERR_DEVICE, "lane setup", e3); }
     }
     {
-        hipError_t e1 = hipHostMalloc(reinterpret_cast<void**>(&ctx->hostTrips), (racc_hip_ctx::kDrainBase + racc_hip_ctx::kDrainRing) * 4, hipHostMallocMapped);
-        if (e1 == hipSuccess) { std::memset(ctx->hostTrips, 0, (racc_hip_ctx::kDrainBase + racc_hip_ctx::kDrainRing) * 4); e1 = hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->devTrips), ctx->hostTrips, 0); }
+        hipError_t e1 = hipHostMalloc(reinterpret_cast<void**>(&ctx->hostTrips), 64, hipHostMallocMapped);
+        if (e1 == hipSuccess) { *ctx->hostTrips = 0; e1 = hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->devTrips), ctx->hostTrips, 0); }
         if (e1 != hipSuccess) { racc_hip_destroy(ctx); return fail(RACC_HIP_ERR_DEVICE, "watchdog word", e1); }
         if (const char* m = std::getenv("RACC_MAX_ITERS")) { const long long v = std::atoll(m); if (v > 0 && v < (1ll << 31)) ctx->maxIters = uint32_t(v); }
     }
@@ -324,8 +316,6 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
         }
         if (e1 == hipSuccess) e1 = hipMalloc(reinterpret_cast<void**>(&ctx->chainCursors), size_t(racc_hip_ctx::kChainRing) * 64);
         if (e1 == hipSuccess) e1 = hipMemset(ctx->chainCursors, 0, size_t(racc_hip_ctx::kChainRing) * 64);
-        if (e1 == hipSuccess) e1 = hipMalloc(reinterpret_cast<void**>(&ctx->chainDrainCounts), size_t(racc_hip_ctx::kDrainRing) * 4);
-        if (e1 == hipSuccess) e1 = hipMemset(ctx->chainDrainCounts, 0, size_t(racc_hip_ctx::kDrainRing) * 4);
         // Round 4: hipMemset of device memory returns before it has run (null stream), and the lanes' streams — non-blocking — do not
         // wait for the null stream.  A context's first chained launches could therefore draw from cursor words that were zeroed UNDER
         // them: chunks handed out twice, the second time after the batch's miss shading had run (tests/test_gpu_parity.py::
@@ -345,7 +335,6 @@ int racc_hip_destroy(racc_hip_ctx* ctx) {
     hipDeviceSynchronize();              // launches given a caller's own stream (racc_hip_intersect_device) included
     if (ctx->hostTrips) hipHostFree(ctx->hostTrips);
     if (ctx->chainDev) hipFree(ctx->chainDev);
-    if (ctx->chainDrainCounts) hipFree(ctx->chainDrainCounts);
     if (ctx->chainStream) hipStreamDestroy(ctx->chainStream);
     if (ctx->chainCursors) hipFree(ctx->chainCursors);
     for (Lane& l : ctx->lanes) freeLane(l);
@@ -630,6 +619,10 @@ int racc_hip_stream_synchronize(racc_hip_ctx* ctx, void* stream) {
     if (!ctx) return fail(RACC_HIP_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device), "hipSetDevice");
     HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize");
+    // a lane whose last launch went to this stream has nothing in flight any more (grid sizing looks at this: a launch issued while another
+    // lane's launch is pending takes the thin grid of an overlapped one — round 6: found by bench.py's gather loop, which waits this way)
+    for (uint32_t i = 0; i < ctx->opts.lanes; ++i)
+        if (ctx->lanes[i].everLaunched && ctx->lanes[i].lastStream == static_cast<hipStream_t>(stream)) ctx->lanes[i].launchPending.store(false, std::memory_order_release);
     return checkWatchdog(ctx);
 }
 

@@ -1,6 +1,6 @@
 """Paced issue: 1M-ray device batches issued every P microseconds instead of back to back.  With the lazy chain a batch issued
-while the chain's kernels are in their drain used to be only PUBLISHED to them — traced by the few long-ray waves still alive.  Round 6: a kernel
-three quarters of whose workgroups have ended no longer counts (drain tracking; RACC_CHAIN_DRAIN=0 restores the old rule for this A/B).
+while the chain's kernels are in their drain is only PUBLISHED to them — traced by the few long-ray waves still alive.  Measured in round 6, with
+and without a finer liveness rule (drain tracking: built, no effect, removed again; both runs in profiles/r06/paced_issue.txt): within 1.17 x the floor.
    python tools/gpu_paced.py            -> one JSON line per (chain mode, pause): ms for 24 batches, the GPU-bound floor beside it"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,7 +38,7 @@ for mode, opt in (("lazy chain", dict()), ("chain, a kernel per launch", dict(ch
         for pause_us in (0, 100, 150, 200, 250, 300, 400, 600, 1000):
             t = min(sequence(pause_us * 1e-6) for _ in range(5))
             bad = sum(int(o.download(orc.RESULT_DTYPE, len(rays))["triangle"].tobytes() != ref["triangle"].tobytes()) for o in outs[::7])
-            print(json.dumps(dict(mode=mode, drain_tracking=os.environ.get("RACC_CHAIN_DRAIN", "1"), pause_us=pause_us, ms=round(t * 1e3, 3), floor_ms=round(max(b2b, N * pause_us * 1e-6) * 1e3, 3),
+            print(json.dumps(dict(mode=mode, pause_us=pause_us, ms=round(t * 1e3, 3), floor_ms=round(max(b2b, N * pause_us * 1e-6) * 1e3, 3),
                                   over_floor=round(t / max(b2b, N * pause_us * 1e-6), 3), wrong_batches=bad)), flush=True)
         for o in outs: o.free()
         d_r.free(); scene.destroy(); env.destroy()
