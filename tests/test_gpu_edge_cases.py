@@ -28,6 +28,7 @@ pytestmark = pytest.mark.gpu
 
 # name -> Context options.  chain_min_rays = 1 makes the device path chain batches of any size (the default threshold is 786,432 rays).
 CONFIGS = {
+    "v8, default options (small batches stand alone)": dict(),
     "v8 (default), lazily chained": dict(chain_min_rays=1),
     "v8 stand-alone": dict(chain_launches=2),
     "v8 chained, a kernel per launch": dict(chain_launches=3, chain_min_rays=1),

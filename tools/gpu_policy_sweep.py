@@ -1,12 +1,13 @@
 """Scheduling-policy sweep on the two figures that matter for a caller issuing batch after batch: the 4M-ray launch (steady
-   state) and 1M-ray launches back to back over the lanes.   python tools/gpu_policy_sweep.py '{"refill_min":20}' ..."""
+   state) and 1M-ray launches back to back over the lanes.   python tools/gpu_policy_sweep.py '{"refill_min":20}' ...
+   RACC_SWEEP_SCENE=city-synth|soup-synth: the same sweep on another scene class (round 6: were the constants tuned to one scene family?)."""
 import json, os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 import rayaccel_amd as ra
 from rayaccel_amd import synth
 from oracle import oracle as orc
-sc = synth.battlefield_synth()
+sc = synth.SCENES[os.environ.get("RACC_SWEEP_SCENE", "battlefield-synth")]()
 host = ra.HostScene(sc["vertices"], sc["indices"], quality=int(os.environ.get("RACC_SWEEP_QUALITY", "1")))
 prim, _ = synth.primary_rays(sc["camera"], 1024, 1024)
 ref = orc.traverse(host.blobs(), prim, threads=16)
