@@ -10,7 +10,8 @@
  * result = (primID, tfar, u, v), primID == RTC_INVALID_GEOMETRY_ID => miss (Scene.cpp:418-440).  Rays are processed in
  * slices of 1024 (cpuTestBatch, RayAccelerator.cpp:438) by `threads` pthreads, as the reference's CPU workers do.
  *
- * Not verifiable here: no Embree to run it against.  It compiles (tests/test_oracle.py) and is exercised the day a box has one.
+ * No Embree exists on any box of this build.  Its plumbing is executed end to end against an API-shaped mock (tests/cpp/embree_api_mock.c,
+ * tests/test_oracle.py: every symbol, the RTCRayHit fields, the slice loop, the result conversion); against a real Embree the day a box has one.
  */
 #include <dlfcn.h>
 #include <pthread.h>
