@@ -11,7 +11,9 @@ from helpers import QUANT_VARIANTS, WIDE_VARIANTS, assert_bit_exact, assert_same
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-sc = synth.battlefield_synth(grid=160, boxes=900, quads=4000)
+# RACC_FUZZ_SCENE=soup-synth|city-synth: another scene class at reduced size (soup: leaves of a dozen pairs, stacks deeper than the LDS part)
+sc = {"soup-synth": lambda: synth.soup_synth(triangles=60000, clusters=24), "city-synth": lambda: synth.city_synth(blocks=22)}.get(
+    os.environ.get("RACC_FUZZ_SCENE", ""), lambda: synth.battlefield_synth(grid=160, boxes=900, quads=4000))()
 host = ra.HostScene(sc["vertices"], sc["indices"], quality=int(os.environ.get("RACC_FUZZ_QUALITY", "1")))      # the quality tree by default: the oracle traverses the same blobs
 blobs = host.blobs()
 prim, _ = synth.primary_rays(sc["camera"], 512, 512)
@@ -21,7 +23,7 @@ pool = pool[rng.permutation(len(pool))]
 ref_pool = orc.traverse(blobs, pool, env=sc["env"], threads=8)
 bad = 0
 for rnd in range(rounds):
-    opt = dict(kernel_variant=int(rng.choice([0, 0, 0, 41, 43, 45, 46, 49, 50, 50, 50, 51, 53, 60, 61, 62, 63] + [v for v in (22, 23, 24, 17, 11, 1, 31, 34, 38) if v in ra.engine.available_variants()])), lanes=int(rng.integers(1, 5)), chain_min_rays=int(rng.choice([0, 1, 1, 5000])), chain_launches=int(rng.choice([0, 0, 0, 3, 2])))      # (0: lazy chain, 3: per-launch kernels, 2: off)
+    opt = dict(kernel_variant=int(rng.choice([0, 0, 0, 41, 43, 45, 46, 49, 50, 50, 50, 51, 53, 60, 61, 62, 63, 70, 70] + [v for v in (22, 23, 24, 17, 11, 1, 31, 34, 38) if v in ra.engine.available_variants()])), lanes=int(rng.integers(1, 5)), chain_min_rays=int(rng.choice([0, 1, 1, 5000])), chain_launches=int(rng.choice([0, 0, 0, 3, 2])))      # (0: lazy chain, 3: per-launch kernels, 2: off)
     if rng.random() < 0.6:
         opt.update(waves_per_simd=int(rng.integers(1, 9)), refill_min=int(rng.integers(1, 65)), leaf_min=int(rng.integers(1, 65)),
                    chunk=int(rng.choice([1, 7, 32, 64, 100, 128, 1000])), tail_active=int(rng.integers(1, 70)),
