@@ -27,7 +27,7 @@ assert BVH2_NODE_DTYPE.itemsize == 48 and GPU_NODE_DTYPE.itemsize == 64 and PAIR
 def build(force=False):
     """Compile oracle/libracc_oracle.so with gcc (building the checker is not using it)."""
     src = os.path.join(_HERE, "racc_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "racc_oracle_simd.c"))):
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "racc_oracle_simd.c")), os.path.getmtime(os.path.join(_HERE, "racc_oracle_simd512.c"))):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libracc_oracle.so"])
     # oracle/_ref: the reference's own traversal kernel, built only where /root/reference exists (this container)
     subprocess.call(["make", "-s", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -52,7 +52,8 @@ def lib():
         _lib.orc_traverse.restype = None
         _lib.orc_traverse_mt.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, u32, u32, u32, u32]
         _lib.orc_traverse_mt.restype = None
-        _lib.orc_traverse_simd_mt.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, u32, u32, u32, u32]
+        _lib.orc_traverse_simd_mt.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, u32, u32, u32, u32, u32]
+        _lib.orc_simd512_available.restype = C.c_int
         _lib.orc_traverse_simd_mt.restype = None
         _lib.orc_simd_available.restype = C.c_int
         _lib.orc_env_sample.argtypes = [vp, u32, u32, vp, vp]
@@ -157,8 +158,13 @@ def simd_available():
     return bool(lib().orc_simd_available())
 
 
-def traverse_simd(scene, rays, env=None, threads=1, repeat=1, out=None):
-    """orc_traverse eight rays at a time in AVX2 (racc_oracle_simd.c): bit-identical to traverse(); bench.py's cpu_baseline kind "simd-port"."""
+def simd_width():
+    """Widest form the host supports: 16 (AVX-512F/DQ/VL, racc_oracle_simd512.c), 8 (AVX2 + FMA, racc_oracle_simd.c) or 0."""
+    return 16 if lib().orc_simd512_available() else (8 if simd_available() else 0)
+
+
+def traverse_simd(scene, rays, env=None, threads=1, repeat=1, out=None, width=8):
+    """orc_traverse eight (AVX2) or sixteen (AVX-512) rays at a time: bit-identical to traverse(); bench.py's cpu_baseline kind "simd-port"."""
     rays = np.ascontiguousarray(rays)
     assert rays.dtype == RAY_DTYPE
     n = len(rays)
@@ -169,7 +175,7 @@ def traverse_simd(scene, rays, env=None, threads=1, repeat=1, out=None):
         env = np.ascontiguousarray(env, dtype=np.float32)
         h, w = env.shape[0], env.shape[1]
         envp = _p(env)
-    lib().orc_traverse_simd_mt(_p(scene["nodes"]), _p(scene["pairs"]), _p(scene["remap"]), envp, w, h, _p(rays), _p(out), n, 1024, threads, repeat)
+    lib().orc_traverse_simd_mt(_p(scene["nodes"]), _p(scene["pairs"]), _p(scene["remap"]), envp, w, h, _p(rays), _p(out), n, 1024, threads, repeat, width)
     return out
 
 

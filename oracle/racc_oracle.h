@@ -99,7 +99,12 @@ void orc_traverse_simd(const orc_gpu_node* nodes, const orc_pair* pairs, const u
 void orc_traverse_simd_mt(const orc_gpu_node* nodes, const orc_pair* pairs, const uint32_t* remap,
                           const float* env, uint32_t envW, uint32_t envH,
                           const orc_ray* rays, orc_result* results, uint32_t count,
-                          uint32_t slice, uint32_t threads, uint32_t repeat);
+                          uint32_t slice, uint32_t threads, uint32_t repeat, uint32_t width /* 8, or 16 where orc_simd512_available() */);
+/* racc_oracle_simd512.c — the same with sixteen rays per zmm register (AVX-512F/DQ/VL hosts: the GPU boxes' EPYC 9575F); bit-identical too. */
+int orc_simd512_available(void);
+void orc_traverse_simd512(const orc_gpu_node* nodes, const orc_pair* pairs, const uint32_t* remap,
+                          const float* env, uint32_t envW, uint32_t envH,
+                          const orc_ray* rays, orc_result* results, uint32_t start, uint32_t end);
 
 /* Kernels.h:213-222 — miss colour for a (clamped) direction; OpenCL
  * CLK_NORMALIZED_COORDS_TRUE | CLAMP_TO_EDGE | FILTER_LINEAR semantics. */

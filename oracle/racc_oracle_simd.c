@@ -258,6 +258,13 @@ static inline __attribute__((always_inline)) int simd_step(lanes_t* Lp, int* idl
         node = _mm256_andnot_si256(done, node);      /* finished lanes: idle */
         _mm256_store_si256((__m256i*)L.node, node);
         _mm256_store_si256((__m256i*)L.head, head);
+#ifndef ORC_SIMD_NO_PREFETCH
+        for (int k = 0; k < LANES; ++k) {      /* the record every lane reads next: on its way while the other groups take their turn */
+            const uint32_t nd = L.node[k];
+            const uintptr_t asPair = (uintptr_t)(pairs + (nd & 0xFFFFFFu)), asNode = (uintptr_t)(nodes + (nd & 0x7FFFFFFFu));
+            _mm_prefetch((const char*)(asPair ^ ((asPair ^ asNode) & (uintptr_t)-(intptr_t)(nd >> 31))), _MM_HINT_T0);      /* no branch: inner or leaf is a coin flip */
+        }
+#endif
         idleMask = _mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpeq_epi32(node, _mm256_setzero_si256())));
         for (int m = _mm256_movemask_ps(_mm256_castsi256_ps(done)); m; m &= m - 1) {
             const int k = __builtin_ctz(m);
@@ -269,18 +276,23 @@ static inline __attribute__((always_inline)) int simd_step(lanes_t* Lp, int* idl
 #undef L
 }
 
-/* Two groups of eight rays in turn: their dependent chains (node fetch -> slab tests -> next node) are independent, so the core overlaps one
- * group's loads with the other's arithmetic. */
+/* ORC_SIMD_GROUPS groups of eight rays in turn: their dependent chains (node fetch -> slab tests -> next node) are independent, so the core
+ * overlaps one group's loads (prefetched at the end of its step) with the others' arithmetic. */
+#ifndef ORC_SIMD_GROUPS
+#define ORC_SIMD_GROUPS 2
+#endif
 void orc_traverse_simd(const orc_gpu_node* nodes, const orc_pair* pairs, const uint32_t* remap,
                        const float* env, uint32_t envW, uint32_t envH,
                        const orc_ray* rays, orc_result* results, uint32_t start, uint32_t end) {
-    static __thread lanes_t G[2];
+    static __thread lanes_t G[ORC_SIMD_GROUPS];
     memset(G, 0, sizeof(G));
     uint32_t next = start;
-    int idle[2] = { 0xFF, 0xFF }, alive0 = 1, alive1 = 1;
-    while (alive0 | alive1) {
-        if (alive0) alive0 = simd_step(&G[0], &idle[0], &next, end, nodes, pairs, remap, env, envW, envH, rays, results);
-        if (alive1) alive1 = simd_step(&G[1], &idle[1], &next, end, nodes, pairs, remap, env, envW, envH, rays, results);
+    int idle[ORC_SIMD_GROUPS], alive[ORC_SIMD_GROUPS], any = 1;
+    for (int g = 0; g < ORC_SIMD_GROUPS; ++g) { idle[g] = 0xFF; alive[g] = 1; }
+    while (any) {
+        any = 0;
+        for (int g = 0; g < ORC_SIMD_GROUPS; ++g)
+            if (alive[g]) any |= alive[g] = simd_step(&G[g], &idle[g], &next, end, nodes, pairs, remap, env, envW, envH, rays, results);
     }
 }
 
@@ -290,6 +302,7 @@ typedef struct {
     const orc_ray* rays; orc_result* results; uint32_t count, slice;
     uint64_t* cursor;
     uint32_t repeat;
+    int wide;      /* 16 lanes (racc_oracle_simd512.c) instead of 8 */
 } simd_job;
 
 static void* simd_worker(void* arg) {
@@ -300,7 +313,8 @@ static void* simd_worker(void* arg) {
         if (k >= perPass * j->repeat) break;
         const uint32_t s = (uint32_t)((k % perPass) * j->slice);
         const uint32_t e = s + j->slice < j->count ? s + j->slice : j->count;
-        orc_traverse_simd(j->nodes, j->pairs, j->remap, j->env, j->envW, j->envH, j->rays, j->results, s, e);
+        if (j->wide) orc_traverse_simd512(j->nodes, j->pairs, j->remap, j->env, j->envW, j->envH, j->rays, j->results, s, e);
+        else orc_traverse_simd(j->nodes, j->pairs, j->remap, j->env, j->envW, j->envH, j->rays, j->results, s, e);
     }
     return 0;
 }
@@ -309,12 +323,12 @@ static void* simd_worker(void* arg) {
 void orc_traverse_simd_mt(const orc_gpu_node* nodes, const orc_pair* pairs, const uint32_t* remap,
                           const float* env, uint32_t envW, uint32_t envH,
                           const orc_ray* rays, orc_result* results, uint32_t count,
-                          uint32_t slice, uint32_t threads, uint32_t repeat) {
+                          uint32_t slice, uint32_t threads, uint32_t repeat, uint32_t width) {
     if (!slice) slice = 1024;
     if (!threads) threads = 1;
     if (!repeat) repeat = 1;
     uint64_t cursor = 0;
-    simd_job job = { nodes, pairs, remap, env, envW, envH, rays, results, count, slice, &cursor, repeat };
+    simd_job job = { nodes, pairs, remap, env, envW, envH, rays, results, count, slice, &cursor, repeat, width == 16 && orc_simd512_available() };
     pthread_t* tid = (pthread_t*)malloc(sizeof(pthread_t) * threads);
     for (uint32_t t = 1; t < threads; ++t) pthread_create(&tid[t], 0, simd_worker, &job);
     simd_worker(&job);

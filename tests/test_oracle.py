@@ -193,13 +193,14 @@ def test_large_coordinates_slivers_and_the_other_scene_classes_match_the_arbiter
         assert_matches_arbiter(orc.traverse(blobs, rays), sc, rays, uv_atol=1e-4)
 
 
-def test_eight_wide_avx2_leg_is_the_scalar_port_bit_for_bit(small_scene, small_blobs):
-    """oracle/racc_oracle_simd.c (bench.py's cpu_baseline kind "simd-port": eight rays at a time, as Scene.cpp:386-428 hands them to
-    rtcIntersect8): every lane does what the scalar port does for its ray — byte-identical records on primaries, bounces, random rays,
+@pytest.mark.parametrize("width", [8, 16])
+def test_simd_legs_are_the_scalar_port_bit_for_bit(small_scene, small_blobs, width):
+    """oracle/racc_oracle_simd.c and racc_oracle_simd512.c (bench.py's cpu_baseline kind "simd-port": eight rays at a time in AVX2, as
+    Scene.cpp:386-428 hands them to rtcIntersect8, or sixteen in AVX-512): every lane does what the scalar port does for its ray — byte-identical records on primaries, bounces, random rays,
     invalid and unbounded rays, with and without a probe image, on both trees, on leaves of 127 pairs (incl. 127 exact-distance ties) and
     on the 40-deep comb, for any thread count."""
-    if not orc.simd_available():
-        pytest.skip("host without AVX2 + FMA")
+    if orc.simd_width() < width:
+        pytest.skip("host without " + ("AVX2 + FMA" if width == 8 else "AVX-512F/DQ/VL"))
     import rayaccel_amd as ra
     prim, _ = synth.primary_rays(small_scene["camera"], 256, 256)
     rays = np.concatenate([prim, synth.diffuse_bounce_rays(small_scene, prim, orc.traverse(small_blobs, prim), 30001), synth.random_rays(20003, seed=7, extent=100.0, ymax=30.0)])
@@ -209,17 +210,17 @@ def test_eight_wide_avx2_leg_is_the_scalar_port_bit_for_bit(small_scene, small_b
         for env in (None, small_scene["env"]):
             want = orc.traverse(blobs, rays, env=env)
             for threads in (1, 3):
-                assert orc.traverse_simd(blobs, rays, env=env, threads=threads).tobytes() == want.tobytes()
-    for n in (1, 5):       # fewer rays than lanes
-        assert orc.traverse_simd(small_blobs, rays[:n]).tobytes() == orc.traverse(small_blobs, rays[:n]).tobytes()
-    assert len(orc.traverse_simd(small_blobs, rays[:0])) == 0
+                assert orc.traverse_simd(blobs, rays, env=env, threads=threads, width=width).tobytes() == want.tobytes()
+    for n in (1, 5, 17):       # fewer rays than lanes
+        assert orc.traverse_simd(small_blobs, rays[:n], width=width).tobytes() == orc.traverse(small_blobs, rays[:n]).tobytes()
+    assert len(orc.traverse_simd(small_blobs, rays[:0], width=width)) == 0
     for arrangement in ("row", "near_last", "coincident"):
         blobs, _ = leaf_scene(127, arrangement)
         r = leaf_rays(127, arrangement)
-        assert orc.traverse_simd(blobs, r).tobytes() == orc.traverse(blobs, r).tobytes()
+        assert orc.traverse_simd(blobs, r, width=width).tobytes() == orc.traverse(blobs, r).tobytes()
     comb = comb_scene(40)
     r = make_rays(np.stack([np.linspace(-20, 20, 300), np.linspace(-15, 15, 300), np.full(300, -10.0)], 1), [[0, 0, 1]] * 300)
-    assert orc.traverse_simd(comb, r).tobytes() == orc.traverse(comb, r).tobytes()
+    assert orc.traverse_simd(comb, r, width=width).tobytes() == orc.traverse(comb, r).tobytes()
 
 
 def test_deep_stack_comb():

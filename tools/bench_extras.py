@@ -395,10 +395,18 @@ def oracle_check_and_cpu_legs(S):
         t_simd, rep_v, out_v = time_leg(lambda o, r: oracle.traverse_simd(blobs, bounce, env=sc["env"], threads=threads, repeat=r, out=o))
         if not np.array_equal(out_v.view(np.uint8), out_s.view(np.uint8)):
             sys.exit("bench: the 8-wide CPU port and the scalar port disagree")
-        cpu_baseline = dict(cpu_baseline, value=round(n / t_simd / 1e6, 2), kind="simd-port",
+        isa, by_width = "avx2", {"avx2_8_lanes": round(n / t_simd / 1e6, 2)}
+        if oracle.simd_width() == 16:       # the same again with 16 rays per zmm register where the host has AVX-512 (the GPU boxes' EPYC 9575F does)
+            t_16, rep_16, out_16 = time_leg(lambda o, r: oracle.traverse_simd(blobs, bounce, env=sc["env"], threads=threads, repeat=r, out=o, width=16))
+            if not np.array_equal(out_16.view(np.uint8), out_s.view(np.uint8)):
+                sys.exit("bench: the 16-wide CPU port and the scalar port disagree")
+            by_width["avx512_16_lanes"] = round(n / t_16 / 1e6, 2)
+            if t_16 < t_simd: isa, t_simd, rep_v = "avx512", t_16, rep_16
+        cpu_baseline = dict(cpu_baseline, value=round(n / t_simd / 1e6, 2), kind="simd-port", isa=isa, mrays_per_s_by_width=by_width,
                             scalar_port_mrays_per_s=cpu_baseline["value"], simd_over_scalar=round(t_scalar / t_simd, 2),
-                            sample="the full 1,048,576-ray batch of the timed workload, %d passes per timing x 3 timings (median), %d pthreads x 1024-ray slices; 8-wide AVX2 packet form "
-                                   "of the oracle's BVH2 traversal (8 rays per packet as Scene.cpp:386-428 hands them to rtcIntersect8), bit-identical to the scalar port "
+                            sample="the full 1,048,576-ray batch of the timed workload, %d passes per timing x 3 timings (median), %d pthreads x 1024-ray slices; SIMD form "
+                                   "of the oracle's BVH2 traversal (one ray per vector lane, 8 as Scene.cpp:386-428 hands them to rtcIntersect8 or 16 where the host has AVX-512: "
+                                   "`value` is the faster, `mrays_per_s_by_width` both), bit-identical to the scalar port "
                                    "(`scalar_port_mrays_per_s`); NOT Embree: the reference's CPU path is binary-only Embree 2.x bvh8/AVX2, unavailable here" % (rep_v, threads))
     try:        # optional row: a system Embree through oracle/embree_adapter.py, if one is installed
         from oracle import embree_adapter

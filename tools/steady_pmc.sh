@@ -1,7 +1,39 @@
 #!/bin/bash
+# tools/steady_pmc.sh                                   what binds the kernel in STEADY STATE -> gpurun_out/steady_state_pmc.json (below)
+# tools/steady_pmc.sh probe <tag> "<counters of pass 1>" "<pass 2>" ...     ad-hoc PMC passes over bench.py's timed launches (RACC_BENCH_ARGS
+#   adds bench flags): each pass its own rocprofv3 run (--pmc only, never combined with traces); prints the mean per traversal launch.
+if [ "$1" = probe ]; then
+shift
+TAG=$1; shift
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$REPO/gpurun_out/pmc_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+CMD="python $REPO/bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 3 ${RACC_BENCH_ARGS}"
+i=0
+for set in "$@"; do
+  i=$((i+1))
+  timeout -k 5 180 rocprofv3 --pmc $set --output-format csv -d "$OUT/p$i" -- $CMD > "$OUT/p$i.log" 2>&1 || tail -3 "$OUT/p$i.log"
+done
+python - "$OUT" <<'PY'
+import collections, csv, glob, json, sys
+out = {}
+for f in glob.glob(sys.argv[1] + "/p*/*/*_counter_collection.csv"):
+    byc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "traverseKernel" in r["Kernel_Name"]:
+            byc[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    for k, v in byc.items():
+        v.sort(); vals = [x[1] for x in v]
+        out[k] = round(sum(vals[4:24]) / max(1, len(vals[4:24])), 1)
+print(json.dumps(out, indent=1))
+json.dump(out, open(sys.argv[1] + "/summary.json", "w"), indent=1)
+PY
+exit 0
+fi
 # What binds the kernel in STEADY STATE (round 5).  profiles/<round>/derived.json describes an isolated 1M-ray launch, a third of which is ramp-up and
 # drain; here the same counters for 8M-ray launches (bench.py --mode strong at N = 1: one 8M-ray batch per step, one lane, no chaining — a launch
-# is 1.65 ms, of which ramp-up and drain are ~8 %).  One rocprofv3 --pmc run per counter set (tools/pmc_probe.sh), condensed with
+# is 1.65 ms, of which ramp-up and drain are ~8 %).  One rocprofv3 --pmc run per counter set (the probe mode above), condensed with
 # tools/summarize_profile.py's formulas into gpurun_out/steady_state_pmc.json (tools/summarize_profile.py copies it into profiles/<round>/).
 cd "${GRAFT_REPO_ROOT:-.}"
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -9,7 +41,7 @@ export RACC_BENCH_ISO_LAUNCHES=0
 SETS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_INSTS_VMEM_WR"
       "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA"
       "GRBM_GUI_ACTIVE GRBM_COUNT" "TA_TA_BUSY_sum TD_TD_BUSY_sum" "TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE")
-RACC_BENCH_ARGS='--mode strong --engine-opts {"lanes":1,"chain_launches":2}' bash tools/pmc_probe.sh steady "${SETS[@]}" > gpurun_out/steady_pmc_raw.json 2>&1
+RACC_BENCH_ARGS='--mode strong --engine-opts {"lanes":1,"chain_launches":2}' bash tools/steady_pmc.sh probe steady "${SETS[@]}" > gpurun_out/steady_pmc_raw.json 2>&1
 python - <<'PY'
 import json
 c = json.load(open("gpurun_out/pmc_steady/summary.json"))
