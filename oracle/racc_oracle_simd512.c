@@ -234,13 +234,6 @@ static inline __attribute__((always_inline)) int simd_step(lanes16_t* Lp, unsign
     node = _mm512_mask_mov_epi32(node, done, zero);      /* finished lanes: idle */
     _mm512_store_si512((void*)L.node, node);
     _mm512_store_si512((void*)L.head, head);
-#ifndef ORC_SIMD_NO_PREFETCH
-    for (int k = 0; k < LANES; ++k) {      /* the record every lane reads next: on its way while the other groups take their turn */
-        const uint32_t nd = L.node[k];
-        const uintptr_t asPair = (uintptr_t)(pairs + (nd & 0xFFFFFFu)), asNode = (uintptr_t)(nodes + (nd & 0x7FFFFFFFu));
-            _mm_prefetch((const char*)(asPair ^ ((asPair ^ asNode) & (uintptr_t)-(intptr_t)(nd >> 31))), _MM_HINT_T0);      /* no branch: inner or leaf is a coin flip */
-    }
-#endif
     *idleMaskP = _mm512_cmpeq_epi32_mask(node, zero);
     for (unsigned m = done; m; m &= m - 1) {
         const int k = __builtin_ctz(m);
