@@ -355,8 +355,12 @@ typedef struct racc_host_build_options {
     uint32_t struct_size;      /* sizeof(racc_host_build_options): fields a caller's older header lacks read as 0 */
     uint32_t quality;          /* 0, 1, 2 */
     uint32_t threads;
-    uint32_t reserved[5];
+    uint32_t split_percent;    /* quality >= 1: spatial splits, the budget of extra triangle references as a percentage of the triangle count;
+                                  0 = RACC_HOST_BUILD_DEFAULT_SPLIT_PERCENT (RACC_BUILD_SPLIT_PERCENT overrides), RACC_HOST_BUILD_NO_SPLITS = none */
+    uint32_t reserved[4];
 } racc_host_build_options;
+#define RACC_HOST_BUILD_DEFAULT_SPLIT_PERCENT 10u
+#define RACC_HOST_BUILD_NO_SPLITS 0xFFFFFFFFu
 int racc_host_scene_build_ex(const float* vertices, uint32_t vertex_count,
                              const uint32_t* indices, uint32_t index_count,
                              const racc_host_build_options* options,      /* NULL = all defaults */

@@ -189,7 +189,7 @@ LIBRARY_DEFAULT_QUALITY = 1      # RACC_HOST_BUILD_DEFAULT_QUALITY (include/racc
 
 class HostBuildOptions(C.Structure):
     """racc_host_build_options (include/racc_hip.h)."""
-    _fields_ = [("struct_size", _u32), ("quality", _u32), ("threads", _u32), ("reserved", _u32 * 5)]
+    _fields_ = [("struct_size", _u32), ("quality", _u32), ("threads", _u32), ("split_percent", _u32), ("reserved", _u32 * 4)]
 
 
 class HostScene:
@@ -199,12 +199,14 @@ class HostScene:
     the LIBRARY's default — what racc::createScene and every other caller of the plain racc_host_scene_build gets: quality 1 since round 6
     (RACC_HOST_BUILD_DEFAULT_QUALITY), RACC_BUILD_QUALITY overrides it; `self.quality` then says which tree was built."""
 
-    def __init__(self, vertices, indices, quality=0, threads=0):
+    def __init__(self, vertices, indices, quality=0, threads=0, split_percent=0):
+        """split_percent (quality >= 1): the spatial-split budget, extra triangle references as a percentage of the triangle count;
+        0 = the library default (RACC_HOST_BUILD_DEFAULT_SPLIT_PERCENT = 10; RACC_BUILD_SPLIT_PERCENT overrides), -1 = no splits."""
         lib = load_library()
         v = _as_verts4(vertices)
         idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
         h = C.c_void_p()
-        if quality is None and not threads:
+        if quality is None and not threads and not split_percent:
             env = os.environ.get("RACC_BUILD_QUALITY")
             self.quality = max(0, int(env)) if env not in (None, "") else LIBRARY_DEFAULT_QUALITY
             _check(lib.racc_host_scene_build(_ptr(v), len(v), _ptr(idx), idx.size, C.byref(h)))
@@ -213,7 +215,8 @@ class HostScene:
                 env = os.environ.get("RACC_BUILD_QUALITY")
                 quality = max(0, int(env)) if env not in (None, "") else LIBRARY_DEFAULT_QUALITY
             self.quality = int(quality)
-            opt = HostBuildOptions(struct_size=C.sizeof(HostBuildOptions), quality=int(quality), threads=int(threads))
+            opt = HostBuildOptions(struct_size=C.sizeof(HostBuildOptions), quality=int(quality), threads=int(threads),
+                                   split_percent=(0xFFFFFFFF if int(split_percent) < 0 else int(split_percent)))
             _check(lib.racc_host_scene_build_ex(_ptr(v), len(v), _ptr(idx), idx.size, C.byref(opt), C.byref(h)))
         try:
             pn, pp, pr = C.c_void_p(), C.c_void_p(), C.c_void_p()
