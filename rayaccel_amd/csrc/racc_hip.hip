@@ -265,7 +265,7 @@ int racc_hip_create(int device, const racc_hip_options* opts, racc_hip_ctx** out
     }
     // How many launches to keep in flight.  HIP streams share hardware queues (GPU_MAX_HW_QUEUES, 4 unless the environment says
     // otherwise), and kernels of two streams on one hardware queue do not overlap.  Measured on 1M-ray diffuse batches back to
-    // back (tools/gpu_overlap.py), ms per batch: 4 queues: 3 lanes x 2 waves per SIMD 0.260, 4 x 2 0.322, 6 x 1 0.349;
+    // back (a round-3 script, since removed: the loop is tools/gpu_policy_sweep.py's), ms per batch: 4 queues: 3 lanes x 2 waves per SIMD 0.260, 4 x 2 0.322, 6 x 1 0.349;
     // 8 queues: 3 x 2 0.260, 4 x 2 0.253, 6 x 1 0.245-0.251, 7 x 1 0.247, 8 x 1 0.32; 16 queues: 6 x 1 0.248, 8 x 1 0.254.
     // So: six thin launches when the runtime was given >= 8 hardware queues, three otherwise.
     {

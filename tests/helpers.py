@@ -52,8 +52,13 @@ def assert_same_closest_hit(got, ref, what="", max_ties=None, arbiter=None):
     the reference's own box test culled although its pair test accepts it (a ray through a box face within rounding): then
     they report a CLOSER hit than the oracle.  Such a record is accepted only with `arbiter` = dict(vertices, indices, rays)
     and only if the double-precision brute force over ALL triangles (SURVEY.md §8(c)'s arbiter) finds its closest hit at the
-    reported distance — i.e. where the reference's traversal itself misses the true closest hit.  Returns the number of
-    records that differ (ties + closer hits)."""
+    reported distance — i.e. where the reference's traversal itself misses the true closest hit.
+
+    A tree built with spatial splits (scene_build.cpp, TriangleSplitter) holds a triangle in several leaves, each with its own pair record —
+    alone in one, paired or at another corner of its pair in the next — and a ray that crosses two of them meets the triangle twice, with
+    operands that differ and results that agree to rounding; which of the two a kernel keeps depends on its visiting order.  The SAME
+    triangle with t within 2e-6 relative (and an absolute floor of an ulp of the coordinates) and u/v within 1e-4 is therefore the same hit
+    (`aliases`, counted apart from the ties: up to 0.5 % of the records).  Returns the number of records that differ (ties + closer hits)."""
     assert got.dtype == ref.dtype == synth.RESULT_DTYPE
     hit_g, hit_r = got["triangle"] != MISS, ref["triangle"] != MISS
     if arbiter is None:
@@ -62,7 +67,10 @@ def assert_same_closest_hit(got, ref, what="", max_ties=None, arbiter=None):
         assert not (hit_r & ~hit_g).any(), "%s: the oracle hits, the engine misses at %s" % (what, np.nonzero(hit_r & ~hit_g)[0][:8])
     diff = (hit_g != hit_r) | (hit_r & ((got["triangle"] != ref["triangle"]) | (got["t"].view(np.uint32) != ref["t"].view(np.uint32)) |
                                         (got["u"].view(np.uint32) != ref["u"].view(np.uint32)) | (got["v"].view(np.uint32) != ref["v"].view(np.uint32))))
-    bad = np.nonzero(diff)[0]
+    alias = diff & hit_g & hit_r & (got["triangle"] == ref["triangle"]) & np.isclose(got["t"], ref["t"], rtol=2e-6, atol=2e-5) & \
+        np.isclose(got["u"], ref["u"], rtol=0, atol=1e-4) & np.isclose(got["v"], ref["v"], rtol=0, atol=1e-4)
+    assert alias.sum() <= max(8, len(ref) // 200), "%s: %d records report the oracle's triangle through another of its references" % (what, alias.sum())
+    bad = np.nonzero(diff & ~alias)[0]
     if max_ties is None:
         max_ties = max(4, len(ref) // 100000)
     assert len(bad) <= max_ties, "%s: %d records differ from the oracle (allowed: %d), e.g. %s" % (what, len(bad), max_ties, bad[:8])
@@ -80,6 +88,29 @@ def assert_same_closest_hit(got, ref, what="", max_ties=None, arbiter=None):
     for f in ("t", "u", "v"):
         np.testing.assert_allclose(got[f][miss], ref[f][miss], rtol=1e-5, atol=1e-5, err_msg="%s miss colour" % what)
     return len(bad)
+
+
+def assert_same_hits_across_trees(a, b, what="", t_floor=2e-6, uv_atol=1e-4, max_other=None):
+    """Two trees over the same triangles, one traversal: same hit/miss but for rays that graze an edge within rounding; the same triangle, or
+    another one at the same distance — or, for a handful of rays, a closer one hit ON ITS EDGE (a barycentric within 2e-5 of zero: the
+    triangle sits alone or at another corner of its pair in that tree, and its edge test rounds the other way); t within 1e-4 relative above a
+    floor of an ulp of the coordinates, u/v within 1e-4.  Returns (hit/miss differences, other-triangle records)."""
+    n = len(a)
+    dis = int(((a["triangle"] == MISS) != (b["triangle"] == MISS)).sum())
+    assert dis <= max(2, n // 100000), "%s: %d hit/miss differences between the trees" % (what, dis)
+    both = (a["triangle"] != MISS) & (b["triangle"] != MISS)
+    other = both & (a["triangle"] != b["triangle"])
+    assert other.sum() <= (max(4, n // 50000) if max_other is None else max_other), "%s: %d primIds differ" % (what, other.sum())
+    tie = np.isclose(a["t"], b["t"], rtol=1e-6, atol=0)
+    nearer = np.where((a["t"] < b["t"])[:, None], np.stack([a["u"], a["v"]], 1), np.stack([b["u"], b["v"]], 1))
+    on_edge = np.minimum(np.minimum(nearer[:, 0], nearer[:, 1]), 1.0 - nearer[:, 0] - nearer[:, 1]) < 2e-5
+    assert (tie | on_edge)[other].all(), "%s: another triangle is only acceptable at the same distance (or a closer one hit on its edge): rays %s" % (what, np.nonzero(other & ~(tie | on_edge))[0][:8])
+    assert (other & ~tie).sum() <= max(2, n // 250000), "%s: %d edge grazers" % (what, (other & ~tie).sum())
+    same = both & ~other
+    np.testing.assert_allclose(b["t"][same], a["t"][same], rtol=1e-4, atol=t_floor, err_msg=what)
+    np.testing.assert_allclose(b["u"][same], a["u"][same], rtol=1e-4, atol=uv_atol, err_msg=what)
+    np.testing.assert_allclose(b["v"][same], a["v"][same], rtol=1e-4, atol=uv_atol, err_msg=what)
+    return dis, int(other.sum())
 
 
 def assert_matches_arbiter(res, scene, rays, rel=1e-4, uv_atol=2e-5):
@@ -283,8 +314,10 @@ def compare_with_reference_kernel(ref, other, what, rel=1e-4, max_ties=None):
     assert diff.sum() <= (max(2, n // 20000) if max_ties is None else max_ties), "%s: %d ties" % (what, diff.sum())
     same = both & ~diff
     np.testing.assert_allclose(other["t"][same], ref["t"][same], rtol=rel, err_msg=what)
-    np.testing.assert_allclose(other["u"][same], ref["u"][same], rtol=rel, atol=2e-6, err_msg=what)
-    np.testing.assert_allclose(other["v"][same], ref["v"][same], rtol=rel, atol=2e-6, err_msg=what)
+    # (u/v floor: in a tree with spatial splits a triangle has several pair records; two arithmetics can keep different ones — 3.8e-5 on one
+    #  of 677,778 hits)
+    np.testing.assert_allclose(other["u"][same], ref["u"][same], rtol=rel, atol=5e-5, err_msg=what)
+    np.testing.assert_allclose(other["v"][same], ref["v"][same], rtol=rel, atol=5e-5, err_msg=what)
     return int(diff.sum())
 
 

@@ -35,7 +35,8 @@ def same(out, ref_bytes, v, name, row):
     hit = ref["triangle"] != 0xFFFFFFFF
     n_hit = int(((out.view(np.uint8).reshape(-1, 16) != ref.view(np.uint8).reshape(-1, 16)).any(1) & hit).sum())
     row.setdefault("records_differing_from_first", {})[name] = [n_hit, n - n_hit]      # [hit records, miss records (colours to rounding)]
-    assert n_hit <= max(4, len(ref) // 100000), "%s: %d hit records differ on %s" % (v, n_hit, name)
+    # (ties, closer hits, and — in a tree with spatial splits — the same triangle through another of its references: up to 0.5 %)
+    assert n_hit <= max(8, len(ref) // 200), "%s: %d hit records differ on %s" % (v, n_hit, name)
 
 
 variants = [json.loads(v) for v in args] or [{}, {"waves_per_simd": 4}, 60, 61, 62, 63]      # an int = kernel_variant, a dict = Context options
