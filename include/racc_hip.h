@@ -348,15 +348,20 @@ int racc_host_scene_build(const float* vertices, uint32_t vertex_count,
  * enlarge the boxes above them least (Bittner et al. 2013; parallel over fixed subtrees, so still deterministic for any thread
  * count).  The blobs stay in the reference's format (Scene.cpp:73-87) and the reference's traversal order applies unchanged: the
  * oracle and the reference's own OpenCL kernel consume them as they are; only the number of node visits and pair tests per ray
- * drops (battlefield-synth, first-bounce rays: 51.1 -> 45.2 visits, 3.44 -> 2.70 pair tests at quality 1).  Hit records of a quality
- * tree equal those of the quality-0 tree up to how a triangle happens to be paired (t/u/v within rounding, primId up to
- * exact-distance ties).  threads 0 = RACC_BUILD_THREADS, else the CPUs this process may use. */
+ * drops (battlefield-synth, first-bounce rays: 51.1 -> 43.9 visits, 3.44 -> 2.43 pair tests at quality 1).  Since round 6 the tree is
+ * built over REFERENCES to triangles: a triangle whose box is much larger than itself gets several, each with the box of the part of it
+ * between two median planes of the scene's box (spatial splits, Karras & Aila 2013; split_percent below), and then sits in several leaves,
+ * its pair record written once per leaf — remap[] names a triangle more than once, pair_count grows by up to the budget.  Hit records of a
+ * quality tree equal those of the quality-0 tree up to how a triangle happens to be paired (t/u/v within rounding, primId up to
+ * exact-distance ties and rays that graze an edge).  threads 0 = RACC_BUILD_THREADS, else the CPUs this process may use. */
 typedef struct racc_host_build_options {
     uint32_t struct_size;      /* sizeof(racc_host_build_options): fields a caller's older header lacks read as 0 */
     uint32_t quality;          /* 0, 1, 2 */
     uint32_t threads;
     uint32_t split_percent;    /* quality >= 1: spatial splits, the budget of extra triangle references as a percentage of the triangle count;
-                                  0 = RACC_HOST_BUILD_DEFAULT_SPLIT_PERCENT (RACC_BUILD_SPLIT_PERCENT overrides), RACC_HOST_BUILD_NO_SPLITS = none */
+                                  0 = the library chooses: RACC_HOST_BUILD_DEFAULT_SPLIT_PERCENT, or three times that where the SAH estimate of the
+                                  tree as built drops by more than 7 % with it (scenes of unconnected, overlapping triangles); RACC_BUILD_SPLIT_PERCENT
+                                  overrides; RACC_HOST_BUILD_NO_SPLITS = none */
     uint32_t reserved[4];
 } racc_host_build_options;
 #define RACC_HOST_BUILD_DEFAULT_SPLIT_PERCENT 10u

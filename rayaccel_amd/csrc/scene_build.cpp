@@ -16,10 +16,12 @@
 // Quality mode (quality >= 1; no counterpart in the reference; quality 1 is what a caller without options gets since round 6 —
 // RACC_HOST_BUILD_DEFAULT_QUALITY, racc_hip.h): the same tree is then
 // post-processed — every leaf is cut down to ONE triangle pair, and subtrees are re-inserted where they enlarge the
-// boxes above them least (insertion-based optimisation after Bittner et al. 2013, in parallel over fixed subtrees).
+// boxes above them least (insertion-based optimisation after Bittner et al. 2013, in parallel over fixed subtrees);
+// before that (round 6) the builder runs over REFERENCES to triangles, a triangle with a box much larger than itself
+// having several (spatial splits after Karras & Aila 2013: TriangleSplitter below).
 // The output is still the reference's 64 B node / 48 B pair / remap format and its traversal order applies unchanged;
-// it is simply a tree with fewer node visits per ray (battlefield-synth: 51.1 -> 45.7 inner visits, 3.44 -> 2.70 pair
-// tests per first-bounce ray).  quality 0 (racc_host_build_options.quality = 0) stays byte-identical to the oracle's restatement of Bvh2.cpp.
+// it is simply a tree with fewer node visits per ray (battlefield-synth: 51.1 -> 43.9 inner visits, 3.44 -> 2.43 pair
+// tests per first-bounce ray; soup-synth 87.7 -> 54.5 and 39.4 -> 8.5).  quality 0 (racc_host_build_options.quality = 0) stays byte-identical to the oracle's restatement of Bvh2.cpp.
 // No GPU code here; this file is plain C++ and is also what racc::createScene uses.
 
 #include "racc_hip.h"
@@ -1140,11 +1142,14 @@ int racc_host_scene_build_ex(const float* vertices, uint32_t vertex_count,
     // Spatial splits (quality >= 1): the budget as a percentage of the triangle count.  options.split_percent 0 = the library default
     // (RACC_HOST_BUILD_DEFAULT_SPLIT_PERCENT; RACC_BUILD_SPLIT_PERCENT overrides it), RACC_HOST_BUILD_NO_SPLITS = none.
     uint32_t splitPercent = 0;
+    bool splitAdaptive = false;      // the library chose the budget: it may choose the larger one (below)
+    constexpr uint32_t kLargeSplitPercent = 3u * RACC_HOST_BUILD_DEFAULT_SPLIT_PERCENT;
     if (opt.quality) {
         splitPercent = opt.split_percent;
         if (splitPercent == 0u) {
             splitPercent = RACC_HOST_BUILD_DEFAULT_SPLIT_PERCENT;
-            if (const char* e = std::getenv("RACC_BUILD_SPLIT_PERCENT")) { const long v = std::atol(e); splitPercent = v > 0 ? uint32_t(std::min(v, 1000L)) : 0u; }
+            splitAdaptive = true;
+            if (const char* e = std::getenv("RACC_BUILD_SPLIT_PERCENT")) { const long v = std::atol(e); splitPercent = v > 0 ? uint32_t(std::min(v, 1000L)) : 0u; splitAdaptive = false; }
         } else if (splitPercent == RACC_HOST_BUILD_NO_SPLITS) splitPercent = 0u;
         else if (splitPercent > 1000u) { set_error("racc_host_build_options.split_percent must be <= 1000 (or RACC_HOST_BUILD_NO_SPLITS)"); return RACC_HIP_ERR_INVALID; }
     }
@@ -1157,20 +1162,35 @@ int racc_host_scene_build_ex(const float* vertices, uint32_t vertex_count,
             const auto t0 = std::chrono::steady_clock::now();
             std::vector<RefBox> entryBox;
             size_t refs = T;
-            if (splitPercent) {
-                // every reference ends up in a leaf of at most one pair: T + budget references can never make 2^24 pairs or more
-                // when that sum stays below 2^24; a larger scene relies on its triangles pairing up and is re-built without splits
-                // should the packer run out of pair ids (attempt 1)
-                std::vector<uint32_t> refTri;
+            // every reference ends up in a leaf of at most one pair: T + budget references can never make 2^24 pairs or more when that sum
+            // stays below 2^24; a larger scene relies on its triangles pairing up and is re-built without splits should the packer run out
+            // of pair ids (attempt 1)
+            auto buildOverReferences = [&](uint32_t percent, std::vector<Bvh2Node>& bvh, std::vector<uint32_t>& tris, std::vector<RefBox>& boxes) -> size_t {
+                std::vector<uint32_t> refTri, order;
                 std::vector<RefBox> refBox;
-                refs = TriangleSplitter(vertices, indices, T, threads).run(uint64_t(T) * splitPercent / 100u, refTri, refBox);
-                if (refs > T) {
-                    std::vector<uint32_t> order;
-                    Bvh2Builder(refBox, threads).run(s->bvh, order);
-                    s->triangles.resize(order.size());
-                    entryBox.resize(order.size());
-                    for (size_t i = 0; i < order.size(); ++i) { s->triangles[i] = refTri[order[i]]; entryBox[i] = refBox[order[i]]; }
-                } else refs = T;
+                const size_t n = TriangleSplitter(vertices, indices, T, threads).run(uint64_t(T) * percent / 100u, refTri, refBox);
+                if (n <= T) return T;
+                Bvh2Builder(refBox, threads).run(bvh, order);
+                tris.resize(order.size());
+                boxes.resize(order.size());
+                for (size_t i = 0; i < order.size(); ++i) { tris[i] = refTri[order[i]]; boxes[i] = refBox[order[i]]; }
+                return n;
+            };
+            if (splitPercent) {
+                refs = buildOverReferences(splitPercent, s->bvh, s->triangles, entryBox);
+                // The library's default budget is the one that never cost much on the scenes measured; where every box overlaps dozens of others
+                // (unconnected triangles: soup-synth) three times as much pays three times over.  The SAH's estimate of the tree as built tells
+                // the two kinds apart — 0.86 of the default's cost with the larger budget on soup-synth, 1.01 on battlefield-synth, 1.03 on
+                // city-synth — so a caller who did not choose a budget gets the larger one where that estimate drops by more than 7 %.
+                if (splitAdaptive && refs > T && uint64_t(T) * (100u + kLargeSplitPercent) / 100u < (1u << 24)) {
+                    std::vector<Bvh2Node> bvh2;
+                    std::vector<uint32_t> tris2;
+                    std::vector<RefBox> boxes2;
+                    const size_t refs2 = buildOverReferences(kLargeSplitPercent, bvh2, tris2, boxes2);
+                    const double c1 = treeCostBytes(s->bvh, 0), c2 = refs2 > T ? treeCostBytes(bvh2, 0) : c1;
+                    if (prof) std::fprintf(stderr, "RayAccelerator profile: split budget %u %%: %.0f expected bytes as built, %u %%: %.0f\n", splitPercent, c1, kLargeSplitPercent, c2);
+                    if (c2 < 0.93 * c1) { s->bvh.swap(bvh2); s->triangles.swap(tris2); entryBox.swap(boxes2); refs = refs2; }
+                }
             }
             if (refs == T) Bvh2Builder(vertices, indices, T, threads).run(s->bvh, s->triangles);
             const auto tq = std::chrono::steady_clock::now();
@@ -1182,7 +1202,7 @@ int racc_host_scene_build_ex(const float* vertices, uint32_t vertex_count,
             if (prof) std::fprintf(stderr, "RayAccelerator profile: scene build %u triangles (%zu references): bvh2 %.3f s, quality %u %.3f s, pack+flatten %.3f s\n", T, refs,
                                    std::chrono::duration<double>(tq - t0).count(), opt.quality, std::chrono::duration<double>(t1 - tq).count(),
                                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
-            if (rc == RACC_HIP_ERR_LIMIT && refs > T && attempt == 0) { delete s; splitPercent = 0; continue; }      // too many pairs with splits: without
+            if (rc == RACC_HIP_ERR_LIMIT && refs > T && attempt == 0) { delete s; splitPercent = 0; splitAdaptive = false; continue; }      // too many pairs with splits: without
             if (rc != RACC_HIP_OK) { delete s; return rc; }
             *out = s;
             return RACC_HIP_OK;

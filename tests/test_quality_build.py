@@ -119,7 +119,7 @@ def test_quality_zero_through_the_options_entry_is_the_reference_build(scene):
     assert a.nodes.tobytes() == b.nodes.tobytes() and a.pairs.tobytes() == b.pairs.tobytes() and a.remap.tobytes() == b.remap.tobytes()
 
 
-SPLITS = [-1, 0, 40]      # HostScene(split_percent=): none, the library default (10 % of the triangle count), a large budget
+SPLITS = [-1, 0, 40]      # HostScene(split_percent=): none, the library's choice (10 % of the triangle count, or 30 %), a large budget
 
 
 @pytest.mark.parametrize("split", SPLITS)
@@ -129,7 +129,7 @@ def test_quality_blobs_are_a_valid_scene(scene, quality, split):
     check_tree(hs, scene, one_pair_leaves=True, splits=split >= 0)
     T = len(scene["indices"].reshape(-1, 3))
     extra = (hs.remap[:2 * hs.pair_count:2] & 0x3FFFFFFF).size + ((hs.remap[1:2 * hs.pair_count:2] >> 30) != 0).sum() - T
-    assert (extra == 0) if split < 0 else (0 < extra <= T * (split or 10) // 100), extra      # references beyond one per triangle: within the budget
+    assert (extra == 0) if split < 0 else (0 < extra <= T * (split or 30) // 100), extra      # references beyond one per triangle: within the budget
 
 
 def test_spatial_splits_on_other_scene_classes():
@@ -199,23 +199,24 @@ def test_quality_tree_costs_less(scene, batches):
 
 
 def test_spatial_splits_pay_where_boxes_overlap():
-    """Unconnected random triangles (soup-synth, 60k): every box overlaps dozens of others.  With the default budget (10 % more references)
-    a first-bounce ray reads >= 8 % fewer bytes than in the same quality tree without splits, with 30 % >= 15 % fewer (measured 12 % / 24 %;
-    at a million triangles 17 % / 31 %)."""
+    """Unconnected random triangles (soup-synth, 60k): every box overlaps dozens of others.  With 10 % more references a first-bounce ray reads
+    >= 8 % fewer bytes than in the same quality tree without splits, with 30 % >= 15 % fewer (measured 12 % / 24 %; at a million triangles
+    17 % / 31 %) — and a caller who names no budget gets the 30 % here (the SAH estimate of the tree as built drops by more than 7 % with it),
+    the 10 % on the battlefield family."""
     sc = synth.soup_synth(triangles=60000, clusters=24)
     prim, _ = synth.primary_rays(sc["camera"], 256, 256)
-    trees = {sp: ra.HostScene(sc["vertices"], sc["indices"], quality=1, split_percent=sp) for sp in (-1, 0, 30)}
+    trees = {sp: ra.HostScene(sc["vertices"], sc["indices"], quality=1, split_percent=sp) for sp in (-1, 0, 10, 30)}
     rays = synth.diffuse_bounce_rays(sc, prim, orc.traverse(trees[-1].blobs(), prim), 32768)
     res = {sp: orc.traverse(h.blobs(), rays, counters=True) for sp, h in trees.items()}
     cost = {sp: 64.0 * r[1].mean() + 48.0 * r[2].mean() for sp, r in res.items()}
-    assert cost[0] < 0.92 * cost[-1] and cost[30] < 0.85 * cost[-1], cost
-    for sp in (0, 30):      # ... and finds the same hits
-        a, b = res[-1][0], res[sp][0]
-        assert ((a["triangle"] == MISS) != (b["triangle"] == MISS)).sum() <= 2
-        both = (a["triangle"] != MISS) & (b["triangle"] != MISS)
-        other = both & (a["triangle"] != b["triangle"])
-        assert np.allclose(a["t"][other], b["t"][other], rtol=1e-6, atol=0) and other.sum() <= 8
-        np.testing.assert_allclose(b["t"][both & ~other], a["t"][both & ~other], rtol=1e-4, atol=0)
+    assert cost[10] < 0.92 * cost[-1] and cost[30] < 0.85 * cost[-1], cost
+    assert trees[0].nodes.tobytes() == trees[30].nodes.tobytes() and trees[0].pairs.tobytes() == trees[30].pairs.tobytes()
+    from helpers import assert_same_hits_across_trees
+    for sp in (10, 30):      # ... and finds the same hits
+        assert_same_hits_across_trees(res[-1][0], res[sp][0], "soup, no splits against %d %%" % sp, max_other=8)
+    bf = synth.battlefield_synth(grid=96, boxes=300, quads=1500)
+    a, b = (ra.HostScene(bf["vertices"], bf["indices"], quality=1, split_percent=sp) for sp in (0, 10))
+    assert a.nodes.tobytes() == b.nodes.tobytes() and a.pairs.tobytes() == b.pairs.tobytes() and a.remap.tobytes() == b.remap.tobytes()
 
 
 def test_quality_tree_of_the_bench_scene_needs_fewer_visits():
@@ -253,7 +254,7 @@ def test_tiny_and_degenerate_inputs():
         sc = dict(vertices=v, indices=idx.reshape(-1, 3))
         hs = ra.HostScene(v, idx, quality=1, split_percent=split)
         check_tree(hs, sc, one_pair_leaves=True, splits=split >= 0)
-        assert hs.pair_count == 100 if split < 0 else 100 < hs.pair_count <= 100 + (split or 10)      # (every reference its own single-triangle pair)
+        assert hs.pair_count == 100 if split < 0 else 100 < hs.pair_count <= 100 + (split or 30)      # (every reference its own single-triangle pair)
         v = np.tile(np.array([[0, 0, 0, 1], [1, 0, 0, 1], [0, 1, 0, 1]], np.float32), (40, 1))
         idx = np.arange(120, dtype=np.uint32)
         sc = dict(vertices=v, indices=idx.reshape(-1, 3))
