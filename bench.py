@@ -360,7 +360,7 @@ def main():
                    "scene_build": ("racc_host_scene_build without options = what racc::createScene performs (library default: quality %d)" % host.quality) if args.quality is None
                                   else "racc_host_scene_build_ex(quality = %d), asked for on the command line" % args.quality,
                    "tree": ("quality %d: %d inner nodes, %d pairs (reference format; " % (host.quality, len(host.nodes), host.pair_count)) +
-                           ("the reference's builder, Bvh2.cpp restated)" if host.quality == 0 else "one pair per leaf + re-inserted subtrees; `reference_builder_tree` = the quality-0 tree in the same loop)"),
+                           ("the reference's builder, Bvh2.cpp restated)" if host.quality == 0 else "built over triangle references (spatial splits), one pair per leaf, subtrees re-inserted; `reference_builder_tree` = the quality-0 tree in the same loop)"),
                    "ray_batches_in_rotation": len(d_sets),
                    "grid_blocks": launch["grid_blocks"], "waves_per_simd": launch["waves_per_simd"], "lanes": lanes,
                    "lanes_in_rotation": ctx.auto_lanes, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},

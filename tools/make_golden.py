@@ -86,7 +86,7 @@ def quality_bytes(quality=1, xl=False):
     res0 = orc.traverse(base.blobs(), prim, threads=8)          # the bench bounces off the primaries' hits; any tree finds the same ones
     res, nv, npairs, depth = orc.traverse(host.blobs(), prim, counters=True, threads=8)
     sec.update(scene=sc["name"], inner_nodes=len(host.nodes), pairs=host.pair_count,
-               what="racc_host_build_options.quality = %d (rayaccel_amd/csrc/scene_build.cpp): one pair per leaf + re-inserted subtrees; reference format, reference traversal order" % quality,
+               what="racc_host_build_options.quality = %d (rayaccel_amd/csrc/scene_build.cpp): spatial splits + one pair per leaf + re-inserted subtrees; reference format, reference traversal order" % quality,
                coherent_1M=dict(bytes=orc.algorithmic_bytes(res, nv, npairs), nv_mean=float(nv.mean()), np_mean=float(npairs.mean()),
                                 hit_rate=float((res["triangle"] != 0xFFFFFFFF).mean()), max_stack=int(depth.max())))
     for s, b in enumerate(synth.diffuse_bounce_batches(sc, prim, res, 1 << 20, range(2))):
