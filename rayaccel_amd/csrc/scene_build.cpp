@@ -43,6 +43,12 @@
 
 #include <sched.h>
 
+// A leaf reference holds a pair index in 24 bits (Scene.cpp:294-312).  (tests/cpp/scene_build_limit.cpp lowers the limit to reach the
+// paths behind it: the build over triangle references falls back to one reference per triangle when the packer runs out of pair ids.)
+#ifndef RACC_SCENE_MAX_PAIRS
+#define RACC_SCENE_MAX_PAIRS (1u << 24)
+#endif
+
 namespace {
 
 void set_error(const char* msg);
@@ -1061,7 +1067,7 @@ int flatten(racc_host_scene& s, const float* vertices, const uint32_t* indices) 
         leafLast[n] = uint32_t(s.pairs.size());
     }
     s.pairCount = uint32_t(s.pairs.size());
-    if (s.pairCount >= (1u << 24)) { set_error("more than 2^24 triangle pairs (Scene.cpp:298)"); return RACC_HIP_ERR_LIMIT; }
+    if (s.pairCount >= RACC_SCENE_MAX_PAIRS) { set_error("more than 2^24 triangle pairs (Scene.cpp:298)"); return RACC_HIP_ERR_LIMIT; }
 
     std::vector<uint32_t> innerIndex(nodeCount, 0);
     s.nodes.clear(); s.nodes.reserve(nodeCount / 2 + 1);
@@ -1182,7 +1188,7 @@ int racc_host_scene_build_ex(const float* vertices, uint32_t vertex_count,
                 // (unconnected triangles: soup-synth) three times as much pays three times over.  The SAH's estimate of the tree as built tells
                 // the two kinds apart — 0.86 of the default's cost with the larger budget on soup-synth, 1.01 on battlefield-synth, 1.03 on
                 // city-synth — so a caller who did not choose a budget gets the larger one where that estimate drops by more than 7 %.
-                if (splitAdaptive && refs > T && uint64_t(T) * (100u + kLargeSplitPercent) / 100u < (1u << 24)) {
+                if (splitAdaptive && refs > T && uint64_t(T) * (100u + kLargeSplitPercent) / 100u < RACC_SCENE_MAX_PAIRS) {
                     std::vector<Bvh2Node> bvh2;
                     std::vector<uint32_t> tris2;
                     std::vector<RefBox> boxes2;

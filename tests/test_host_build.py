@@ -196,6 +196,21 @@ def test_scene_build_under_thread_sanitizer(tsan_builds):
     assert p.returncode == 0 and "ThreadSanitizer" not in p.stderr, p.stdout + p.stderr[-3000:]
 
 
+def test_the_build_at_the_pair_limit_falls_back_to_one_reference_per_triangle(tmp_path):
+    """A leaf reference holds a pair index in 24 bits (Scene.cpp:294-312).  A scene whose pairs fit but not with the extra references of the
+    spatial splits (battlefield-synth-XL is 10 % away from that) must come out as the build without splits gives it, not fail: the limit
+    lowered to 2,000 pairs in a build of scene_build.cpp of its own (tests/cpp/scene_build_limit.cpp) — library's budget, a caller's budget,
+    a caller without options; and the error past the limit."""
+    import subprocess
+    exe = str(tmp_path / "scene_build_limit")
+    p = subprocess.run(["g++", "-O1", "-std=c++17", "-Wno-subobject-linkage", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "scene_build_limit.cpp"),
+                        "-o", exe, "-lpthread"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "the blobs of the build without splits" in p.stdout and "rc -4" in p.stdout
+
+
 def _device_to_reference(dev):
     """64 B device records (racc_host_scene_device_nodes) back into the reference's node format (Scene.cpp:73-78)."""
     out = np.zeros(len(dev), ra.engine.GPU_NODE_DTYPE)
