@@ -283,6 +283,25 @@ def test_callers_without_options_get_the_quality_tree_and_the_environment_can_sw
     assert int(re.search(r"#define RACC_HOST_BUILD_DEFAULT_QUALITY (\d+)u", header).group(1)) == ra.engine.LIBRARY_DEFAULT_QUALITY
 
 
+def test_the_split_budget_can_be_set_from_outside(scene, monkeypatch):
+    """RACC_BUILD_SPLIT_PERCENT stands in for a budget the caller did not name (options.split_percent = 0, or no options at all): 0 = no
+    splits, n = that percentage, and then the library does not pick the larger budget on its own; a budget in the options wins."""
+    same = lambda a, b: a.nodes.tobytes() == b.nodes.tobytes() and a.pairs.tobytes() == b.pairs.tobytes() and a.remap.tobytes() == b.remap.tobytes()
+    monkeypatch.delenv("RACC_BUILD_SPLIT_PERCENT", raising=False)
+    monkeypatch.delenv("RACC_BUILD_QUALITY", raising=False)
+    none, p25 = (ra.HostScene(scene["vertices"], scene["indices"], quality=1, split_percent=sp) for sp in (-1, 25))
+    assert not same(none, p25)
+    monkeypatch.setenv("RACC_BUILD_SPLIT_PERCENT", "0")
+    assert same(ra.HostScene(scene["vertices"], scene["indices"], quality=1), none) and same(ra.HostScene(scene["vertices"], scene["indices"], quality=None), none)
+    assert same(ra.HostScene(scene["vertices"], scene["indices"], quality=1, split_percent=25), p25)
+    monkeypatch.setenv("RACC_BUILD_SPLIT_PERCENT", "25")
+    assert same(ra.HostScene(scene["vertices"], scene["indices"], quality=1), p25) and same(ra.HostScene(scene["vertices"], scene["indices"], quality=None), p25)
+    assert same(ra.HostScene(scene["vertices"], scene["indices"], quality=1, split_percent=-1), none)
+    q0 = ra.HostScene(scene["vertices"], scene["indices"], quality=0)
+    monkeypatch.setenv("RACC_BUILD_SPLIT_PERCENT", "300")
+    assert same(ra.HostScene(scene["vertices"], scene["indices"], quality=0), q0)      # the reference's builder has no splits
+
+
 def test_options_are_validated(scene):
     lib = ra.load_library()
     v = ra.engine._as_verts4(scene["vertices"])
