@@ -269,6 +269,25 @@ def test_sliver_triangles(contexts):
     assert_matches_arbiter(ref, sc, rays, rel=5e-3, uv_atol=1e-2)
 
 
+def test_needles_and_far_coordinates_on_trees_with_spatial_splits(contexts):
+    """The same two scenes through the library's default build (quality 1: a needle 60 long and 1e-6 wide is cut into dozens of references, each
+    in a leaf of its own; box planes at 1e5 move in steps of 0.008): every instantiation against the oracle on the same blobs — the V8 family
+    bit for bit, the wide kernels up to ties and to the same triangle reached through another of its references — and the arbiter's hits."""
+    sc = sliver_scene()
+    hs = ra.HostScene(sc["vertices"], sc["indices"], quality=1, split_percent=60)
+    assert hs.pair_count > 1.3 * len(sc["indices"].reshape(-1, 3))
+    rays = synth.random_rays(20000, seed=3, extent=50.0, ymax=50.0)
+    rays["origin"][:, 1] -= 25
+    ref = run_everywhere(contexts, hs.blobs(), rays, "slivers, split tree", arbiter=sc, max_ties=8, reference_ties=8)
+    assert (ref["triangle"] != MISS).sum() > 100
+    assert_matches_arbiter(ref, sc, rays, rel=5e-3, uv_atol=1e-2)
+    sc = far_scene()
+    hs = ra.HostScene(sc["vertices"], sc["indices"], quality=1)
+    prim, _ = synth.primary_rays(sc["camera"], 128, 128)
+    ref = run_everywhere(contexts, hs.blobs(), prim, "coordinates at 1e4..1e5, split tree", env=sc["env"][::8, ::8].copy(), arbiter=sc, max_ties=8, reference_ties=8)
+    assert_matches_arbiter(ref, sc, prim, uv_atol=1e-4)
+
+
 def test_paced_issue_does_not_starve_the_chain(contexts):
     """ADVICE (round 5): a caller that issues 1M-ray batches at about the GPU's pace — each one while the chain's kernels are in their drain,
     alive with a few long-ray waves — must not have its batches traced by those few waves.  Same results, and the paced sequence may

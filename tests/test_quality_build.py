@@ -12,7 +12,7 @@ import pytest
 import rayaccel_amd as ra
 from oracle import oracle as orc
 from rayaccel_amd import synth
-from helpers import MISS, assert_matches_arbiter
+from helpers import MISS, assert_matches_arbiter, far_scene, sliver_scene
 
 
 def _geometry_boxes(sc):
@@ -196,6 +196,31 @@ def test_quality_tree_costs_less(scene, batches):
     assert npairs[1] < 0.9 * npairs[0] and npairs[2] < 0.9 * npairs[0], npairs
     bytes_ = [orc.algorithmic_bytes(r[0], r[1], r[2]) for r in (base, q1, q2)]
     assert bytes_[1] < bytes_[0] and bytes_[2] < bytes_[0]
+
+
+@pytest.mark.parametrize("split", [0, 60])
+def test_spatial_splits_of_needles_and_of_coordinates_at_1e5(split):
+    """Where the clipping has least to work with: 3,000 needles of length 5 .. 60 and width 1e-6 .. 1e-1 in random orientation (nearly all of
+    their boxes is empty: they take the whole budget, up to dozens of cuts each), and the small battlefield scene scaled by 1000 and moved to
+    (5e4, 2e4, -7e4), where a binary32 box plane moves in steps of 0.004 .. 0.016.  Valid trees, every sampled point of every triangle inside a
+    leaf box of its triangle, and the arbiter's hits (to the tolerances the reference builder's tree is held to on these scenes)."""
+    sl = sliver_scene()
+    hs = ra.HostScene(sl["vertices"], sl["indices"], quality=1, split_percent=split)
+    check_tree(hs, sl, one_pair_leaves=True, splits=True)
+    assert hs.pair_count > len(sl["indices"].reshape(-1, 3))
+    rays = synth.random_rays(20000, seed=3, extent=50.0, ymax=50.0)
+    rays["origin"][:, 1] -= 25
+    res = orc.traverse(hs.blobs(), rays)
+    assert (res["triangle"] != MISS).sum() > 100
+    assert_matches_arbiter(res, sl, rays, rel=5e-3, uv_atol=1e-2)
+    base, n0, p0, _ = orc.traverse(orc.build_scene(sl["vertices"], sl["indices"]), rays, counters=True)
+    _, n1, p1, _ = orc.traverse(hs.blobs(), rays, counters=True)
+    assert 64.0 * n1.mean() + 48.0 * p1.mean() < 0.8 * (64.0 * n0.mean() + 48.0 * p0.mean()), (n0.mean(), p0.mean(), n1.mean(), p1.mean())      # ... and what the splits are for
+    far = far_scene()
+    hs = ra.HostScene(far["vertices"], far["indices"], quality=1, split_percent=split)
+    check_tree(hs, far, one_pair_leaves=True, splits=True)
+    prim, _ = synth.primary_rays(far["camera"], 128, 128)
+    assert_matches_arbiter(orc.traverse(hs.blobs(), prim), far, prim, uv_atol=1e-4)      # (an ulp of these coordinates is 0.008: u/v to 4.7e-5 with a triangle's other corner as p0)
 
 
 def test_spatial_splits_pay_where_boxes_overlap():
